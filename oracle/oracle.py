@@ -1,0 +1,228 @@
+"""ctypes front-end of the CPU ORACLE (test infrastructure, NOT the product).
+
+Loads ``oracle/librmh_oracle.so`` (built from ``rmh_oracle.c`` by
+``oracle/Makefile``; rebuilt on demand with gcc).  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import this module; nothing under ``riemann_amd/`` does.
+
+Array conventions here are the reference's: theta is ``(N, d)`` row-major,
+histories are ``(T+1, N, d)`` with entry 0 the state on entry to ``run``
+(/root/reference/riemann/samplers/sampler.py:49-54).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librmh_oracle.so")
+_lib = None
+
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "rmh_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "librmh_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_SO)
+    vp, i64, u64, dbl, i32 = C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_int
+    L.orc_log.restype = dbl
+    L.orc_log.argtypes = [dbl]
+    L.orc_sincos2pi.argtypes = [dbl, C.POINTER(dbl), C.POINTER(dbl)]
+    L.orc_rng_seed.argtypes = [u64, u64, i64, _u64p]
+    L.orc_rng_stream.argtypes = [_u64p, i64, i32, i32, _f64p, _f64p]
+    L.orc_model_gaussian.restype = vp
+    L.orc_model_gaussian.argtypes = [_f64p, _f64p, i32]
+    L.orc_model_logreg.restype = vp
+    L.orc_model_logreg.argtypes = [_f64p, _f64p, i64, i32, dbl]
+    L.orc_model_changepoint.restype = vp
+    L.orc_model_changepoint.argtypes = [_f64p, _f64p, i32, i32, dbl, dbl, dbl, dbl, dbl]
+    L.orc_model_free.argtypes = [vp]
+    L.orc_model_dim.argtypes = [vp]
+    for name in ("orc_log_prior", "orc_log_likelihood", "orc_log_posterior",
+                 "orc_grad_log_posterior"):
+        getattr(L, name).argtypes = [vp, _f64p, i64, _f64p]
+    L.orc_changepoint_indices.argtypes = [vp, _f64p, i64, _i32p]
+    L.orc_proposal_rw.restype = vp
+    L.orc_proposal_rw.argtypes = [_f64p, i32, dbl]
+    L.orc_proposal_hmc.restype = vp
+    L.orc_proposal_hmc.argtypes = [dbl, i32, i32]
+    L.orc_proposal_free.argtypes = [vp]
+    L.orc_propose.argtypes = [vp, vp, _f64p, i64, _u64p, _f64p, _f64p]
+    L.orc_run.restype = i32
+    L.orc_run.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, vp, vp, vp, i32]
+    L.orc_max_threads.restype = i32
+    _lib = L
+    return L
+
+
+def _c(a, dtype=np.float64):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+# --------------------------------------------------------------------- RNG --
+def rng_seed(seed, N, chain0=0):
+    """(N, 16) uint64 state: 4 xoshiro256++ sub-streams per chain."""
+    st = np.empty((N, 16), dtype=np.uint64)
+    lib().orc_rng_seed(seed, chain0, N, st)
+    return st
+
+
+def rng_stream(state, d, T):
+    """Advance ``state`` by T iterations; returns xi (T,N,d), u (T,N)."""
+    N = state.shape[0]
+    xi = np.empty((T, N, d))
+    u = np.empty((T, N))
+    lib().orc_rng_stream(state, N, d, T, xi, u)
+    return xi, u
+
+
+def olog(x):
+    return lib().orc_log(float(x))
+
+
+def sincos2pi(u):
+    s, c = C.c_double(), C.c_double()
+    lib().orc_sincos2pi(float(u), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+# ------------------------------------------------------------------ models --
+class _Model:
+    def __init__(self, handle):
+        self._h = handle
+        self.d = lib().orc_model_dim(handle)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_model_free(self._h)
+            self._h = None
+
+    def _eval(self, fn, theta, grad=False):
+        th = _c(np.atleast_2d(theta))
+        N = th.shape[0]
+        out = np.empty((N, self.d) if grad else (N,))
+        getattr(lib(), fn)(self._h, th, N, out)
+        return out
+
+    def log_prior(self, theta):
+        return self._eval("orc_log_prior", theta)
+
+    def log_likelihood(self, theta):
+        return self._eval("orc_log_likelihood", theta)
+
+    def log_posterior(self, theta):
+        return self._eval("orc_log_posterior", theta)
+
+    def grad_log_posterior(self, theta):
+        return self._eval("orc_grad_log_posterior", theta, grad=True)
+
+
+class Gaussian(_Model):
+    """MultiGaussianDist(mu, C): /root/reference/riemann/models/gaussian.py:21-58."""
+
+    def __init__(self, mu, Cov):
+        mu = _c(np.atleast_1d(mu))
+        Lc = _c(np.linalg.cholesky(np.atleast_2d(Cov)))
+        super().__init__(lib().orc_model_gaussian(mu, Lc, len(mu)))
+
+
+class LogReg(_Model):
+    """Logistic regression with N(0, tau2 I) prior (new plugin)."""
+
+    def __init__(self, X, y, tau2):
+        X = _c(X)
+        y = _c(y)
+        super().__init__(lib().orc_model_logreg(X, y, X.shape[0], X.shape[1], float(tau2)))
+
+
+class Changepoint(_Model):
+    """ChangepointRegression1D, fixed k: /root/reference/riemann/models/changepoint.py:81-181.
+    theta packs (cpx[k], cpv[k+1], sig)."""
+
+    def __init__(self, x, y, k, xmin, xmax, lamb, alpha, beta):
+        x = _c(x)
+        y = _c(y)
+        self.n = len(x)
+        super().__init__(lib().orc_model_changepoint(
+            x, y, len(x), k, float(xmin), float(xmax), float(lamb), float(alpha), float(beta)))
+
+    def indices(self, theta):
+        th = _c(np.atleast_2d(theta))
+        idx = np.empty((th.shape[0], self.n), dtype=np.int32)
+        lib().orc_changepoint_indices(self._h, th, th.shape[0], idx)
+        return idx
+
+
+# --------------------------------------------------------------- proposals --
+class _Proposal:
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_proposal_free(self._h)
+            self._h = None
+
+    def propose(self, model, theta, rng_state):
+        th = _c(np.atleast_2d(theta))
+        N, d = th.shape
+        thp = np.empty_like(th)
+        logq = np.empty(N)
+        lib().orc_propose(self._h, model._h, th, N, rng_state, thp, logq)
+        return thp, logq
+
+
+class RandomWalk(_Proposal):
+    """MetropolisRandomWalk(C): /root/reference/riemann/proposals/randomwalk.py:12-26."""
+
+    def __init__(self, Cov, scale=1.0):
+        Lc = _c(np.linalg.cholesky(np.atleast_2d(Cov)))
+        self.d = Lc.shape[0]
+        self._h = lib().orc_proposal_rw(Lc, self.d, float(scale))
+
+
+class HMC(_Proposal):
+    """VanillaHMC(eps, Nsteps, grad, M=None): /root/reference/riemann/proposals/hamiltonian.py:55-91.
+    Nsteps=1 is MALA."""
+
+    def __init__(self, eps, nsteps, d):
+        self.d = d
+        self._h = lib().orc_proposal_hmc(float(eps), int(nsteps), int(d))
+
+
+# ----------------------------------------------------------------- sampler --
+def run(model, proposal, theta, logpost, rng_state, T, history=True, nthreads=0):
+    """Sampler.run over N chains (/root/reference/riemann/samplers/sampler.py:44-90).
+
+    ``theta`` (N,d), ``logpost`` (N,), ``rng_state`` (N,16) are advanced in
+    place.  Returns (hist_theta (T+1,N,d), hist_logpost (T+1,N), accept (T,N))
+    or (None, None, accept) with ``history=False``.
+    """
+    N, d = theta.shape
+    assert theta.flags.c_contiguous and logpost.flags.c_contiguous
+    ht = np.empty((T + 1, N, d)) if history else None
+    hl = np.empty((T + 1, N)) if history else None
+    acc = np.empty((T, N), dtype=np.uint8)
+    rc = lib().orc_run(model._h, proposal._h, N, theta, logpost, rng_state, T,
+                       ht.ctypes.data if history else None,
+                       hl.ctypes.data if history else None,
+                       acc.ctypes.data, nthreads)
+    if rc != 0:
+        raise ValueError("oracle: model and proposal dimensions differ")
+    return ht, hl, acc
+
+
+def max_threads():
+    return lib().orc_max_threads()

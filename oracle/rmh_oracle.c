@@ -1,0 +1,606 @@
+/*
+ * rmh_oracle.c -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * A plain-C restatement of the rscalzo/riemann Metropolis-Hastings hot path
+ *   Sampler.run() -> Sampler.sample() -> Proposal.propose() -> Model.log_posterior()
+ * extended from one chain to N independent chains.  Only tests/, the smoke
+ * check in __graft_entry__.py and bench.py's `cpu_baseline` leg may load this
+ * library; nothing under riemann_amd/ links, imports or calls it.
+ *
+ * Parity status: PINNED.  the .npz files under tests/golden/ were produced by importing the
+ * reference itself (tests/golden/make_golden.py) with this file's random
+ * stream injected through np.random.normal / np.random.uniform;
+ * tests/test_oracle_golden.py checks this restatement against those files.
+ * The logistic-regression Model has no reference counterpart (SURVEY.md
+ * section 8a-9): its arithmetic is pinned by the spec in DESIGN.md and a
+ * long-double cross-check only; the MALA/HMC/accept logic around it is pinned
+ * by driving it through the reference's own Sampler + VanillaHMC.
+ *
+ * Every function cites the reference lines it restates (paths relative to
+ * /root/reference).  Floating-point contraction must be OFF when compiling
+ * (-ffp-contract=off): the random-number spec below is defined operation by
+ * operation (explicit fma where the spec says fma) so that the HIP kernels
+ * reproduce the same doubles bit for bit.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* 1. "rmh-rng v1": 4 xoshiro256++ sub-streams per chain                       */
+/* ------------------------------------------------------------------------- */
+/*
+ * The reference draws from numpy's process-global MT19937:
+ *   d normals   proposals/randomwalk.py:25, proposals/hamiltonian.py:79
+ *   1 uniform   samplers/sampler.py:84
+ * in that order, every iteration.  A global generator cannot be shared by 10^5
+ * chains, so the build defines its own stream (SURVEY.md 8b "Threading", 8c
+ * "RNG parity mechanism") and injects it into the reference when the golden
+ * vectors are made:
+ *
+ *   chain c (GLOBAL chain id) owns sub-streams g = 0..3, stream id 4c+g;
+ *   every iteration each sub-stream draws P = ceil(ceil(d/4)/2) Box-Muller
+ *   pairs; normal number m (0..2P-1) of sub-stream g is coordinate j = 4m+g
+ *   (dropped when j >= d); afterwards sub-stream 0 draws one more 64-bit word
+ *   for the accept uniform.
+ *
+ * Four sub-streams because the HIP kernels put a chain on the four lanes
+ * {c, c+16, c+32, c+48} of a wavefront (the B-operand layout of
+ * v_mfma_f64_16x16x4_f64), each lane owning the coordinates j = g (mod 4).
+ */
+typedef uint64_t u64;
+
+#define ORC_GAMMA 0x9E3779B97F4A7C15ULL
+
+static inline u64 orc_mix64(u64 z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+static inline u64 orc_rotl(u64 x, int k) { return (x << k) | (x >> (64 - k)); }
+
+/* state words of stream `sid` under `seed` */
+static void orc_stream_init(u64 seed, u64 sid, u64 s[4])
+{
+    u64 x = orc_mix64(orc_mix64(seed + ORC_GAMMA) + sid);
+    for (int i = 0; i < 4; i++) {
+        x += ORC_GAMMA;
+        s[i] = orc_mix64(x);
+    }
+}
+
+/* xoshiro256++ (Blackman & Vigna 2019) */
+static inline u64 orc_next(u64 s[4])
+{
+    const u64 r = orc_rotl(s[0] + s[3], 23) + s[0];
+    const u64 t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = orc_rotl(s[3], 45);
+    return r;
+}
+
+static inline double orc_from_bits(u64 b) { double d; memcpy(&d, &b, 8); return d; }
+static inline u64 orc_to_bits(double d) { u64 b; memcpy(&b, &d, 8); return b; }
+
+/* natural log, defined operation by operation (fdlibm-style reduction,
+ * k*ln2 + log1p(f) with s = f/(2+f)); < 1 ulp.  Specials follow IEEE/numpy:
+ * log(<0)=nan, log(0)=-inf, log(inf)=inf, log(nan)=nan. */
+double orc_log(double x)
+{
+    static const double
+        ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+        Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+        Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+        Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+        Lg7 = 1.479819860511658591e-01;
+    if (x != x) return x;
+    if (x < 0.0) return NAN;
+    if (x == 0.0) return -INFINITY;
+    if (x == INFINITY) return x;
+    int k = 0;
+    u64 ix = orc_to_bits(x);
+    if (ix < 0x0010000000000000ULL) { /* subnormal */
+        x *= 0x1p54;
+        k = -54;
+        ix = orc_to_bits(x);
+    }
+    k += (int)(ix >> 52) - 1023;
+    u64 mant = ix & 0x000FFFFFFFFFFFFFULL;
+    double m;
+    if (mant >= 0x0006A09E667F3BCDULL) { /* m in [sqrt(2)/2, 1) */
+        m = orc_from_bits(mant | 0x3FE0000000000000ULL);
+        k += 1;
+    } else {                             /* m in [1, sqrt(2)) */
+        m = orc_from_bits(mant | 0x3FF0000000000000ULL);
+    }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
+}
+
+/* sin(2 pi u), cos(2 pi u) for u in [0,1), defined operation by operation. */
+void orc_sincos2pi(double u, double *sn, double *cs)
+{
+    static const double
+        TWO_PI = 6.283185307179586476925,
+        S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+        S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+        S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10,
+        C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+        C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+        C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double q = floor(fma(4.0, u, 0.5));      /* nearest quarter turn, 0..4 */
+    const double r = fma(-0.25, q, u);             /* exact, |r| <= 1/8 */
+    const double x = r * TWO_PI;                   /* |x| <= pi/4 */
+    const double z = x * x;
+    const double ps = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
+    const double sx = fma(x * z, fma(z, ps, S1), x);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    const double zz = z * z;
+    const double cx = 1.0 - fma(-zz, pc, 0.5 * z); /* 1 - (z/2 - z^2 pc) */
+    switch (((int)q) & 3) {
+    case 0: *sn = sx;  *cs = cx;  break;
+    case 1: *sn = cx;  *cs = -sx; break;
+    case 2: *sn = -sx; *cs = -cx; break;
+    default: *sn = -cx; *cs = sx; break;
+    }
+}
+
+#define ORC_2M53 0x1p-53
+
+/* one Box-Muller pair from one sub-stream */
+static inline void orc_pair(u64 s[4], double *z0, double *z1)
+{
+    const u64 a = orc_next(s), b = orc_next(s);
+    const double u1 = (double)((a >> 11) + 1) * ORC_2M53; /* (0,1] */
+    const double u2 = (double)(b >> 11) * ORC_2M53;       /* [0,1) */
+    const double r = sqrt(-2.0 * orc_log(u1));
+    double sn, cs;
+    orc_sincos2pi(u2, &sn, &cs);
+    *z0 = r * cs;
+    *z1 = r * sn;
+}
+
+/* d normals for one chain; st = 16 words [g][4]. */
+void orc_rng_normals(u64 *st, int d, double *xi)
+{
+    const int P = ((d + 3) / 4 + 1) / 2;
+    for (int g = 0; g < 4; g++)
+        for (int p = 0; p < P; p++) {
+            double z0, z1;
+            orc_pair(st + 4 * g, &z0, &z1);
+            const int j0 = 4 * (2 * p) + g, j1 = 4 * (2 * p + 1) + g;
+            if (j0 < d) xi[j0] = z0;
+            if (j1 < d) xi[j1] = z1;
+        }
+}
+
+/* U[0,1) from sub-stream 0 */
+double orc_rng_uniform(u64 *st) { return (double)(orc_next(st) >> 11) * ORC_2M53; }
+
+void orc_rng_seed(u64 seed, u64 chain0, int64_t N, u64 *state)
+{
+    for (int64_t c = 0; c < N; c++)
+        for (int g = 0; g < 4; g++)
+            orc_stream_init(seed, 4 * (chain0 + (u64)c) + (u64)g, state + 16 * c + 4 * g);
+}
+
+/* the per-iteration stream as the reference consumes it: xi (T,N,d), u (T,N) */
+void orc_rng_stream(u64 *state, int64_t N, int d, int T, double *xi, double *u)
+{
+    for (int t = 0; t < T; t++)
+        for (int64_t c = 0; c < N; c++) {
+            orc_rng_normals(state + 16 * c, d, xi + ((int64_t)t * N + c) * d);
+            u[(int64_t)t * N + c] = orc_rng_uniform(state + 16 * c);
+        }
+}
+
+/* ------------------------------------------------------------------------- */
+/* 2. Models                                                                   */
+/* ------------------------------------------------------------------------- */
+enum { ORC_GAUSS = 1, ORC_LOGREG = 2, ORC_CHANGEPOINT = 3 };
+
+typedef struct orc_model {
+    int kind, d;
+    /* gaussian: models/gaussian.py:27-44 */
+    double *mu, *L, logdetC;
+    /* logreg (new plugin) */
+    int64_t n;
+    double *X, *y, tau2;
+    /* changepoint: models/changepoint.py:86-104 */
+    int k; /* number of changepoints; pieces = k+1 */
+    double *cx, *cy, xmin, xmax, lamb, alpha, beta;
+} orc_model;
+
+static double *orc_dup(const double *p, size_t n)
+{
+    double *q = (double *)malloc(n * sizeof(double));
+    memcpy(q, p, n * sizeof(double));
+    return q;
+}
+
+/* models/gaussian.py:27-44: caller passes L = cholesky(C) (lower, row-major) */
+orc_model *orc_model_gaussian(const double *mu, const double *L, int d)
+{
+    orc_model *m = (orc_model *)calloc(1, sizeof(*m));
+    m->kind = ORC_GAUSS;
+    m->d = d;
+    m->mu = orc_dup(mu, d);
+    m->L = orc_dup(L, (size_t)d * d);
+    double s = 0;
+    for (int i = 0; i < d; i++) s += log(L[i * d + i]);
+    m->logdetC = 2 * s; /* gaussian.py:43 */
+    return m;
+}
+
+orc_model *orc_model_logreg(const double *X, const double *y, int64_t n, int d, double tau2)
+{
+    orc_model *m = (orc_model *)calloc(1, sizeof(*m));
+    m->kind = ORC_LOGREG;
+    m->d = d;
+    m->n = n;
+    m->X = orc_dup(X, (size_t)n * d);
+    m->y = orc_dup(y, n);
+    m->tau2 = tau2;
+    return m;
+}
+
+orc_model *orc_model_changepoint(const double *x, const double *y, int n, int k,
+                                 double xmin, double xmax, double lamb,
+                                 double alpha, double beta)
+{
+    orc_model *m = (orc_model *)calloc(1, sizeof(*m));
+    m->kind = ORC_CHANGEPOINT;
+    m->k = k;
+    m->d = 2 * k + 2;
+    m->n = n;
+    m->cx = orc_dup(x, n);
+    m->cy = orc_dup(y, n);
+    m->xmin = xmin; m->xmax = xmax; m->lamb = lamb; m->alpha = alpha; m->beta = beta;
+    return m;
+}
+
+void orc_model_free(orc_model *m)
+{
+    if (!m) return;
+    free(m->mu); free(m->L); free(m->X); free(m->y); free(m->cx); free(m->cy);
+    free(m);
+}
+
+int orc_model_dim(const orc_model *m) { return m->d; }
+
+/* u = solve(L, theta-mu): models/gaussian.py:49-51 (np.linalg.solve on the
+ * lower-triangular factor; restated as forward substitution) */
+static void orc_gauss_u(const orc_model *m, const double *th, double *u)
+{
+    const int d = m->d;
+    for (int i = 0; i < d; i++) {
+        double acc = th[i] - m->mu[i];
+        for (int j = 0; j < i; j++) acc -= m->L[i * d + j] * u[j];
+        u[i] = acc / m->L[i * d + i];
+    }
+}
+
+/* numpy searchsorted(a, v) side='left' (changepoint.py:181) */
+static inline int orc_searchsorted(const double *a, int n, double v)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+/* log_prior of one chain */
+static double orc_log_prior1(const orc_model *m, const double *th)
+{
+    switch (m->kind) {
+    case ORC_GAUSS:
+        return 0.0; /* gaussian.py:46-47 */
+    case ORC_LOGREG: {
+        double s = 0;
+        for (int j = 0; j < m->d; j++) s += th[j] * th[j];
+        return -s / (2.0 * m->tau2);
+    }
+    case ORC_CHANGEPOINT: { /* changepoint.py:128-160 */
+        const int kc = m->k, kp = kc + 1; /* k = len(cpv) = number of pieces */
+        const double *cpx = th, *cpv = th + kc, sig = th[2 * kc + 1];
+        const double logP_k = kp * log(m->lamb) - lgamma((double)kp) - m->lamb;
+        double logP_v = 0; /* log_gamma_dist, changepoint.py:18-19 */
+        for (int j = 0; j < kp; j++)
+            logP_v += m->alpha * log(m->beta) + (m->alpha - 1) * log(cpv[j])
+                      - m->beta * cpv[j] - lgamma(m->alpha);
+        const double Lx = m->xmax - m->xmin;
+        double sumlog = 0, prev = m->xmin;
+        for (int j = 0; j <= kc; j++) {
+            const double cur = (j < kc) ? cpx[j] : m->xmax;
+            sumlog += log(cur - prev);
+            prev = cur;
+        }
+        const double logP_s = lgamma(2.0 * kp + 1) + sumlog - kp * log(Lx);
+        double logP_sig2 = log(1.0 / (sig * sig));
+        if (sig < 0) logP_sig2 = NAN;
+        double logP = logP_k + logP_v + logP_s + logP_sig2;
+        if (logP != logP) logP = -INFINITY;
+        return logP;
+    }
+    }
+    return NAN;
+}
+
+static inline double orc_log1pexp(double e) /* log(1+exp(e)) */
+{
+    return e > 0 ? e + log1p(exp(-e)) : log1p(exp(e));
+}
+
+static double orc_log_lik1(const orc_model *m, const double *th, double *scratch)
+{
+    switch (m->kind) {
+    case ORC_GAUSS: { /* gaussian.py:49-52 */
+        const int d = m->d;
+        orc_gauss_u(m, th, scratch);
+        double uu = 0;
+        for (int i = 0; i < d; i++) uu += scratch[i] * scratch[i];
+        return -0.5 * (uu + d * log(2 * M_PI) + m->logdetC);
+    }
+    case ORC_LOGREG: {
+        double ll = 0;
+        for (int64_t i = 0; i < m->n; i++) {
+            const double *xr = m->X + i * m->d;
+            double eta = 0;
+            for (int j = 0; j < m->d; j++) eta += xr[j] * th[j];
+            ll += m->y[i] * eta - orc_log1pexp(eta);
+        }
+        return ll;
+    }
+    case ORC_CHANGEPOINT: { /* changepoint.py:106-126, predict :175-181 */
+        const int kc = m->k, n = (int)m->n;
+        const double *cpx = th, *cpv = th + kc, sig = th[2 * kc + 1];
+        const double sig2 = sig * sig;
+        double ss = 0;
+        for (int i = 0; i < n; i++) {
+            const double r = cpv[orc_searchsorted(cpx, kc, m->cx[i])] - m->cy[i];
+            ss += (r * r) / sig2;
+        }
+        double logL = -0.5 * (ss + n * log(sig2) + n * log(2 * M_PI));
+        if (logL != logL) logL = -INFINITY;
+        return logL;
+    }
+    }
+    return NAN;
+}
+
+/* Model.log_posterior, models/model.py:43-55 */
+static double orc_log_post1(const orc_model *m, const double *th, double *scratch)
+{
+    const double lp = orc_log_prior1(m, th), ll = orc_log_lik1(m, th, scratch);
+    if (isinf(lp) || isnan(lp) || isinf(ll) || isnan(ll)) return -INFINITY;
+    return lp + ll;
+}
+
+/* gradient of log posterior of one chain.
+ * gaussian: grad_log_likelihood, gaussian.py:54-58 (log_prior = 0). */
+static void orc_grad1(const orc_model *m, const double *th, double *g, double *scratch)
+{
+    const int d = m->d;
+    switch (m->kind) {
+    case ORC_GAUSS: {
+        double *u = scratch;
+        orc_gauss_u(m, th, u);
+        for (int i = d - 1; i >= 0; i--) { /* v = solve(L.T, u) */
+            double acc = u[i];
+            for (int j = i + 1; j < d; j++) acc -= m->L[j * d + i] * g[j];
+            g[i] = acc / m->L[i * d + i];
+        }
+        for (int i = 0; i < d; i++) g[i] = -g[i];
+        break;
+    }
+    case ORC_LOGREG: {
+        for (int j = 0; j < d; j++) g[j] = 0;
+        for (int64_t i = 0; i < m->n; i++) {
+            const double *xr = m->X + i * d;
+            double eta = 0;
+            for (int j = 0; j < d; j++) eta += xr[j] * th[j];
+            const double sg = eta >= 0 ? 1.0 / (1.0 + exp(-eta)) : exp(eta) / (1.0 + exp(eta));
+            const double r = m->y[i] - sg;
+            for (int j = 0; j < d; j++) g[j] += xr[j] * r;
+        }
+        for (int j = 0; j < d; j++) g[j] -= th[j] / m->tau2;
+        break;
+    }
+    default:
+        for (int j = 0; j < d; j++) g[j] = NAN; /* no gradient (changepoint.py:108-113) */
+    }
+}
+
+void orc_log_prior(const orc_model *m, const double *theta, int64_t N, double *out)
+{
+    for (int64_t c = 0; c < N; c++) out[c] = orc_log_prior1(m, theta + c * m->d);
+}
+
+void orc_log_likelihood(const orc_model *m, const double *theta, int64_t N, double *out)
+{
+    double *scratch = (double *)malloc(sizeof(double) * m->d);
+    for (int64_t c = 0; c < N; c++) out[c] = orc_log_lik1(m, theta + c * m->d, scratch);
+    free(scratch);
+}
+
+void orc_log_posterior(const orc_model *m, const double *theta, int64_t N, double *out)
+{
+    double *scratch = (double *)malloc(sizeof(double) * m->d);
+    for (int64_t c = 0; c < N; c++) out[c] = orc_log_post1(m, theta + c * m->d, scratch);
+    free(scratch);
+}
+
+void orc_grad_log_posterior(const orc_model *m, const double *theta, int64_t N, double *out)
+{
+    double *scratch = (double *)malloc(sizeof(double) * m->d);
+    for (int64_t c = 0; c < N; c++) orc_grad1(m, theta + c * m->d, out + c * m->d, scratch);
+    free(scratch);
+}
+
+/* integer path of changepoint.predict (changepoint.py:181): piece index per datum */
+void orc_changepoint_indices(const orc_model *m, const double *theta, int64_t N, int32_t *idx)
+{
+    for (int64_t c = 0; c < N; c++)
+        for (int i = 0; i < (int)m->n; i++)
+            idx[c * m->n + i] = orc_searchsorted(theta + c * m->d, m->k, m->cx[i]);
+}
+
+/* ------------------------------------------------------------------------- */
+/* 3. Proposals                                                                */
+/* ------------------------------------------------------------------------- */
+enum { ORC_RW = 1, ORC_HMC = 2 };
+
+typedef struct orc_proposal {
+    int kind, d;
+    double *L, scale; /* MetropolisRandomWalk: randomwalk.py:17-19 */
+    double eps;       /* VanillaHMC: hamiltonian.py:60-74 (M=None only) */
+    int nsteps;
+} orc_proposal;
+
+orc_proposal *orc_proposal_rw(const double *L, int d, double scale)
+{
+    orc_proposal *p = (orc_proposal *)calloc(1, sizeof(*p));
+    p->kind = ORC_RW; p->d = d; p->L = orc_dup(L, (size_t)d * d); p->scale = scale;
+    return p;
+}
+
+orc_proposal *orc_proposal_hmc(double eps, int nsteps, int d)
+{
+    orc_proposal *p = (orc_proposal *)calloc(1, sizeof(*p));
+    p->kind = ORC_HMC; p->d = d; p->eps = eps; p->nsteps = nsteps;
+    return p;
+}
+
+void orc_proposal_free(orc_proposal *p)
+{
+    if (!p) return;
+    free(p->L);
+    free(p);
+}
+
+/* Proposal.propose for one chain given its normals xi: returns logqratio.
+ * RW : randomwalk.py:21-26.   HMC: hamiltonian.py:76-91 + leapfrog :13-52,
+ * gradient callable = the model's grad of the log posterior. */
+static double orc_propose1(const orc_proposal *p, const orc_model *m, const double *th,
+                           const double *xi, double *thp, double *work)
+{
+    const int d = p->d;
+    if (p->kind == ORC_RW) {
+        for (int i = 0; i < d; i++) {
+            double acc = 0; /* np.dot(L, xi) */
+            for (int j = 0; j < d; j++) acc += p->L[i * d + j] * xi[j];
+            thp[i] = th[i] + p->scale * acc;
+        }
+        return 0.0;
+    }
+    double *mom = work, *g = work + d, *scr = work + 2 * d;
+    const double eps = p->eps;
+    orc_grad1(m, th, g, scr);
+    for (int i = 0; i < d; i++) mom[i] = xi[i] + 0.5 * eps * g[i]; /* :27 */
+    for (int i = 0; i < d; i++) thp[i] = th[i] + eps * mom[i];     /* :30 */
+    for (int s = 0; s < p->nsteps - 1; s++) {                      /* :34-38 */
+        orc_grad1(m, thp, g, scr);
+        for (int i = 0; i < d; i++) mom[i] = mom[i] + eps * g[i];
+        for (int i = 0; i < d; i++) thp[i] = thp[i] + eps * mom[i];
+    }
+    orc_grad1(m, thp, g, scr);
+    for (int i = 0; i < d; i++) mom[i] = mom[i] + 0.5 * eps * g[i]; /* :40 */
+    double k1 = 0, k0 = 0;
+    for (int i = 0; i < d; i++) { k1 += mom[i] * mom[i]; k0 += xi[i] * xi[i]; }
+    return 0.5 * (k1 - k0); /* :89 */
+}
+
+/* standalone propose over N chains, consuming the chains' streams */
+void orc_propose(const orc_proposal *p, const orc_model *m, const double *theta, int64_t N,
+                 u64 *rng, double *theta_p, double *logq)
+{
+    const int d = p->d;
+    double *xi = (double *)malloc(sizeof(double) * d * 4);
+    for (int64_t c = 0; c < N; c++) {
+        orc_rng_normals(rng + 16 * c, d, xi);
+        logq[c] = orc_propose1(p, m, theta + c * d, xi, theta_p + c * d, xi + d);
+    }
+    free(xi);
+}
+
+/* ------------------------------------------------------------------------- */
+/* 4. Sampler.run over N chains: samplers/sampler.py:44-90                     */
+/* ------------------------------------------------------------------------- */
+/*
+ * theta (N,d), logpost (N), rng (N,16) are updated in place.
+ * hist_theta ((T+1),N,d) / hist_logpost ((T+1),N): entry 0 is the state on
+ * entry (sampler.py:49-50 keeps the last state as element 0), entries 1..T the
+ * states appended by sample() (:89); either may be NULL.  accept (T,N) uint8.
+ * Accept rule, sampler.py:83-84: mhratio = min(0, D) with PYTHON min, i.e.
+ * D if D < 0 else 0 (so NaN -> 0 -> accept); accept iff log(U) < mhratio.
+ */
+int orc_run(const orc_model *m, const orc_proposal *p, int64_t N, double *theta,
+            double *logpost, u64 *rng, int T, double *hist_theta, double *hist_logpost,
+            uint8_t *accept, int nthreads)
+{
+    const int d = m->d;
+    if (p->d != d) return -1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+    {
+        double *work = (double *)malloc(sizeof(double) * d * 6);
+        double *xi = work, *thp = work + d, *w2 = work + 2 * d;
+#pragma omp for schedule(static)
+        for (int64_t c = 0; c < N; c++) {
+            double *th = theta + c * d;
+            u64 *st = rng + 16 * c;
+            if (hist_theta) memcpy(hist_theta + c * d, th, sizeof(double) * d);
+            if (hist_logpost) hist_logpost[c] = logpost[c];
+            for (int t = 0; t < T; t++) {
+                orc_rng_normals(st, d, xi);
+                const double logq = orc_propose1(p, m, th, xi, thp, w2);
+                const double lp_prop = orc_log_post1(m, thp, w2);
+                const double delta = lp_prop - logpost[c] - logq;
+                const double mh = (delta < 0) ? delta : 0.0;
+                const double u = orc_rng_uniform(st);
+                const int acc = orc_log(u) < mh;
+                if (acc) {
+                    memcpy(th, thp, sizeof(double) * d);
+                    logpost[c] = lp_prop;
+                }
+                if (accept) accept[(int64_t)t * N + c] = (uint8_t)acc;
+                if (hist_theta)
+                    memcpy(hist_theta + ((int64_t)(t + 1) * N + c) * d, th, sizeof(double) * d);
+                if (hist_logpost) hist_logpost[(int64_t)(t + 1) * N + c] = logpost[c];
+            }
+        }
+        free(work);
+    }
+    return 0;
+}
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running THE REFERENCE.
+
+Run in the build container only (the reference never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python3 tests/golden/make_golden.py
+
+What it does: imports rscalzo/riemann from /root/reference, replaces
+``np.random.normal`` / ``np.random.uniform`` (looked up at call time at
+riemann/proposals/randomwalk.py:25, riemann/proposals/hamiltonian.py:79 and
+riemann/samplers/sampler.py:84) by functions that replay the build's own
+"rmh-rng v1" stream (oracle/rmh_oracle.c section 1), runs the reference's
+``Sampler`` once per chain and records inputs and outputs as small ``.npz``
+files.  Only data is written: no reference source text is stored.
+
+Fixture ids follow SURVEY.md section 8c (G1..G7).
+"""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+from oracle import oracle as orc  # noqa: E402  (stream source only)
+from riemann_amd.workloads import changepoint_data, logreg_data  # noqa: E402
+
+import riemann  # noqa: E402  (the reference)
+from riemann import Model, ParameterError, Sampler  # noqa: E402
+from riemann.models.gaussian import MultiGaussianDist  # noqa: E402
+from riemann.models import benchmarks as rbench  # noqa: E402
+from riemann.proposals.hamiltonian import VanillaHMC  # noqa: E402
+from riemann.proposals.randomwalk import MetropolisRandomWalk  # noqa: E402
+
+
+# ----------------------------------------------------------- stream replay --
+class Replay:
+    """Feeds one chain's (xi[t], u[t]) to the reference in consumption order."""
+
+    def __init__(self, xi, u):
+        self.xi, self.u, self.tn, self.tu = xi, u, 0, 0
+
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        v = self.xi[self.tn]
+        self.tn += 1
+        shape = (size,) if np.isscalar(size) else tuple(size)
+        assert v.shape == shape, (v.shape, shape)
+        return v.copy()
+
+    def uniform(self, low=0.0, high=1.0, size=None):
+        assert size is None
+        v = self.u[self.tu]
+        self.tu += 1
+        return float(v)
+
+
+def run_reference(model, make_proposal, theta0, seed, T, runs=None):
+    """Run the reference Sampler for every chain on the injected stream.
+
+    theta0 (N,d).  ``runs`` = list of (Nsamples, Nburn, Nthin) executed back to
+    back on the same Sampler (default one run of T).  Returns dict with the
+    stream and, per run, thetas/logpost histories and accept flags."""
+    theta0 = np.atleast_2d(np.asarray(theta0, dtype=np.float64))
+    N, d = theta0.shape
+    runs = runs or [(T, 0, 1)]
+    Ttot = sum(r[0] for r in runs)
+    st = orc.rng_seed(seed, N)
+    xi, u = orc.rng_stream(st, d, Ttot)
+    out = {"seed": np.uint64(seed), "theta0": theta0, "xi": xi, "u": u}
+    per_run = [dict(thetas=[], logpost=[], accept=[]) for _ in runs]
+    real_normal, real_uniform = np.random.normal, np.random.uniform
+    try:
+        for c in range(N):
+            rp = Replay(xi[:, c], u[:, c])
+            np.random.normal, np.random.uniform = rp.normal, rp.uniform
+            s = Sampler(model, make_proposal(), theta0[c].copy())
+            for k, (ns, nb, nt) in enumerate(runs):
+                first = s._chain_thetas[-1]
+                s.run(ns, nb, nt)
+                per_run[k]["thetas"].append(np.array(s._chain_thetas))
+                per_run[k]["logpost"].append(np.array(s._chain_logpost, dtype=np.float64))
+                if nb == 0 and nt == 1:
+                    th = s._chain_thetas
+                    assert th[0] is first
+                    # rejected steps re-append the same object (sampler.py:86-89)
+                    per_run[k]["accept"].append(
+                        np.array([th[t + 1] is not th[t] for t in range(ns)], dtype=np.uint8))
+            assert rp.tn == Ttot and rp.tu == Ttot
+    finally:
+        np.random.normal, np.random.uniform = real_normal, real_uniform
+    for k, pr in enumerate(per_run):
+        sfx = "" if len(runs) == 1 else "_run%d" % k
+        out["thetas" + sfx] = np.stack(pr["thetas"], axis=1)    # (Tk, N, d)
+        out["logpost" + sfx] = np.stack(pr["logpost"], axis=1)  # (Tk, N)
+        if pr["accept"]:
+            out["accept" + sfx] = np.stack(pr["accept"], axis=1)  # (T, N)
+    return out
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("%-28s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+# -------------------------------------------------- G0: the stream itself --
+def g0_rng():
+    arrs = {}
+    for d in (1, 2, 5, 12, 100):
+        st = orc.rng_seed(12345, 3, chain0=7)
+        arrs["state0_d%d" % d] = st.copy()
+        xi, u = orc.rng_stream(st, d, 3)
+        arrs["xi_d%d" % d], arrs["u_d%d" % d], arrs["state3_d%d" % d] = xi, u, st.copy()
+    save("g0_rng", seed=np.uint64(12345), chain0=np.uint64(7), **arrs)
+
+
+# ----------------------------------------------- G1/G2: random-walk Gaussian --
+def g1_gauss2d_rw():
+    """cfg1: benchmark_gauss2d_iso (models/benchmarks.py:15) + MetropolisRandomWalk(I2)."""
+    r = run_reference(rbench.benchmark_gauss2d_iso, lambda: MetropolisRandomWalk(np.eye(2)),
+                      np.ones((4, 2)), seed=0, T=64)
+    save("g1_gauss2d_rw", mu=np.zeros(2), C=np.eye(2), Cprop=np.eye(2), **r)
+
+
+def corr100():
+    return 0.1 * np.eye(100) + 0.9 * np.ones((100, 100))  # models/benchmarks.py:25-26
+
+
+def g2_gauss100d_rw():
+    """cfg2 at fixture size: benchmark_gauss100d_corr + RW with C=(2.38^2/100) C_target."""
+    Ct = corr100()
+    Cp = (2.38 ** 2 / 100.0) * Ct
+    th0 = np.random.default_rng(1).standard_normal((8, 100)) @ np.linalg.cholesky(Ct).T
+    r = run_reference(rbench.benchmark_gauss100d_corr, lambda: MetropolisRandomWalk(Cp),
+                      th0, seed=1, T=32)
+    save("g2_gauss100d_rw", mu=np.zeros(100), prop_factor=np.float64(2.38 ** 2 / 100.0), **r)
+
+
+# -------------------------------------------------- G3: HMC / MALA, Gaussian --
+def g3_gauss_hmc():
+    Ct = corr100()
+    th0 = np.random.default_rng(3).standard_normal((4, 100)) @ np.linalg.cholesky(Ct).T
+    m = rbench.benchmark_gauss100d_corr
+    for tag, eps, L in (("mala", 0.25, 1), ("hmc10", 0.28, 10)):
+        r = run_reference(m, lambda: VanillaHMC(eps, L, m.grad_log_likelihood), th0,
+                          seed=30 + L, T=16)
+        save("g3_gauss100d_" + tag, eps=np.float64(eps), nsteps=np.int64(L), **r)
+    # the model of examples/test_randomwalk.py:32-37, non-adaptive HMC
+    m2 = rbench.benchmark_gauss2d_corr
+    r = run_reference(m2, lambda: VanillaHMC(0.6, 5, m2.grad_log_likelihood),
+                      np.ones((4, 2)), seed=35, T=48)
+    save("g3_gauss2d_hmc5", eps=np.float64(0.6), nsteps=np.int64(5), mu=np.zeros(2),
+         C=0.1 * np.eye(2) + 0.9 * np.ones((2, 2)), **r)
+
+
+# ------------------------------------------ G4: logistic regression plugin --
+class LogRegModel(Model):
+    """The build's logistic-regression plugin, written against the reference's
+    Model ABC (models/model.py:4-64).  NOT in the reference:
+    logL = sum y*eta - log(1+exp(eta)), eta = X beta; logP = -|beta|^2/(2 tau2)."""
+
+    def __init__(self, X, y, tau2):
+        self.X, self.y, self.tau2 = X, y, tau2
+
+    def log_prior(self, theta):
+        return -np.dot(theta, theta) / (2.0 * self.tau2)
+
+    def log_likelihood(self, theta):
+        eta = self.X @ theta
+        return np.sum(self.y * eta - np.logaddexp(0.0, eta))
+
+    def grad_log_posterior(self, theta):
+        eta = self.X @ theta
+        sg = np.where(eta >= 0, 1.0 / (1.0 + np.exp(-np.abs(eta))),
+                      np.exp(-np.abs(eta)) / (1.0 + np.exp(-np.abs(eta))))
+        return self.X.T @ (self.y - sg) - theta / self.tau2
+
+
+def digest(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def g4_logreg():
+    X, y = logreg_data(256, 16, seed=2)
+    m = LogRegModel(X, y, 100.0)
+    th0 = 0.1 * np.random.default_rng(4).standard_normal((4, 16))
+    for tag, eps, L in (("mala", 0.6, 1), ("hmc10", 0.6, 10)):
+        r = run_reference(m, lambda: VanillaHMC(eps, L, m.grad_log_posterior), th0,
+                          seed=40 + L, T=32)
+        save("g4_logreg256x16_" + tag, X=X, y=y, tau2=np.float64(100.0), eps=np.float64(eps),
+             nsteps=np.int64(L), **r)
+    # full size (cfg3/cfg4 data): data regenerated from the seed
+    Xf, yf = logreg_data(10000, 100, seed=2)
+    mf = LogRegModel(Xf, yf, 100.0)
+    # start near stationarity: 300 MALA sweeps of the oracle from 0 (theta0 is stored)
+    om = orc.LogReg(Xf, yf, 100.0)
+    th0 = np.zeros((2, 100))
+    orc.run(om, orc.HMC(0.1, 1, 100), th0, om.log_posterior(th0), orc.rng_seed(9, 2), 300,
+            history=False)
+    for tag, eps, L in (("mala", 0.16, 1), ("hmc10", 0.15, 10)):
+        r = run_reference(mf, lambda: VanillaHMC(eps, L, mf.grad_log_posterior), th0,
+                          seed=50 + L, T=6)
+        r.pop("xi")
+        save("g4_logreg10000x100_" + tag, data_seed=np.int64(2), n=np.int64(10000),
+             d=np.int64(100), X_sha256=digest(Xf), y_sha256=digest(yf), tau2=np.float64(100.0),
+             eps=np.float64(eps), nsteps=np.int64(L), **r)
+
+
+# ----------------------------------------------------------- G5: changepoint --
+def import_changepoint():
+    """riemann/models/changepoint.py needs `autograd` (absent) and does
+    `from ..riemann import Model` (module does not exist): SURVEY.md 8c.
+    Container-local stand-ins for those two IMPORTS only; every line of the
+    model's arithmetic that runs is the reference's own."""
+    ag = types.ModuleType("autograd")
+    ag.numpy = np
+    ag.jacobian = lambda f: (lambda p: (_ for _ in ()).throw(NotImplementedError()))
+    sys.modules["autograd"] = ag
+    sys.modules["autograd.numpy"] = np
+    sys.modules["riemann.riemann"] = riemann
+    from riemann.models import changepoint as cp
+    return cp
+
+
+class PackedChangepoint(Model):
+    """Adapter: a packed vector (cpx[k], cpv[k+1], sig) in front of the
+    reference's ChangepointRegression1D (theta there is a ChangepointParams)."""
+
+    def __init__(self, cp, model, k):
+        self.cp, self.m, self.k = cp, model, k
+
+    def unpack(self, v):
+        k = self.k
+        return self.cp.ChangepointParams(v[:k], v[k:2 * k + 1], v[2 * k + 1])
+
+    def log_prior(self, v):
+        return self.m.log_prior(self.unpack(v))
+
+    def log_likelihood(self, v):
+        return self.m.log_likelihood(self.unpack(v))
+
+
+def scaled_rw(Cdiag, scale):
+    p = MetropolisRandomWalk(np.diag(Cdiag))
+    p.scale = scale  # public attribute, proposals/randomwalk.py:18
+    return p
+
+
+def changepoint_setup(cp, k=5):
+    """riemann/test_changepoint.py:137-150,167 on the seeded cfg5 data."""
+    x, y, truth, Cdiag = changepoint_data(seed=3, k=k)
+    model = cp.ChangepointRegression1D(x, y, 1.0, 3.0, 1.0 * k, 2 * k, 1, 1)
+    return model, x, y, truth, Cdiag
+
+
+def g5_changepoint():
+    cp = import_changepoint()
+    k = 5
+    model, x, y, truth, Cdiag = changepoint_setup(cp)
+    pm = PackedChangepoint(cp, model, k)
+    g = np.random.default_rng(55)
+    th = truth + 0.05 * g.standard_normal((64, 2 * k + 2))
+    th[:, :k] = np.sort(th[:, :k], axis=1)
+    th[40:44, 0], th[40:44, 1] = th[40:44, 1].copy(), th[40:44, 0].copy()  # unsorted cpx
+    th[44:48, k + 2] = [-0.3, 0.0, -1e-9, -2.0]                           # cpv <= 0
+    th[48:52, -1] = [-0.1, -1.0, 0.0, -1e-12]                             # sig <= 0
+    th[52, 0] = 0.5                                                       # cpx < xmin
+    th[53, k - 1] = 3.5                                                   # cpx > xmax
+    th[54, 1] = th[54, 0]                                                 # coincident changepoints
+    logL = np.array([pm.log_likelihood(v) for v in th], dtype=np.float64)
+    logP = np.array([pm.log_prior(v) for v in th], dtype=np.float64)
+    logpost = np.array([pm.log_posterior(v) for v in th], dtype=np.float64)
+    idx = np.array([np.searchsorted(v[:k], x) for v in th], dtype=np.int32)
+    common = dict(x=x, y=y, k=np.int64(k), xmin=np.float64(1.0), xmax=np.float64(3.0),
+                  lamb=np.float64(k), alpha=np.float64(1.0), beta=np.float64(1.0))
+    save("g5_changepoint_eval", theta=th, logL=logL, logP=logP, logpost=logpost, idx=idx,
+         truth=truth, **common)
+    # alpha != 1 exercises (alpha-1)*log(cpv)
+    model2 = cp.ChangepointRegression1D(x, y, 1.0, 3.0, 4.0, 2 * k, 2.5, 1.5)
+    pm2 = PackedChangepoint(cp, model2, k)
+    save("g5_changepoint_eval_a25", theta=th,
+         logL=np.array([pm2.log_likelihood(v) for v in th], dtype=np.float64),
+         logP=np.array([pm2.log_prior(v) for v in th], dtype=np.float64),
+         logpost=np.array([pm2.log_posterior(v) for v in th], dtype=np.float64),
+         **dict(common, lamb=np.float64(4.0), alpha=np.float64(2.5), beta=np.float64(1.5)))
+    th0 = truth + 0.01 * g.standard_normal((4, 2 * k + 2))
+    th0[:, :k] = np.sort(th0[:, :k], axis=1)
+    r = run_reference(pm, lambda: scaled_rw(Cdiag, 0.1), th0, seed=5, T=64)
+    save("g5_changepoint_rw", Cdiag=Cdiag, scale=np.float64(0.1), **common, **r)
+    return cp, pm, Cdiag, th0, common
+
+
+# ------------------------------------------------------------ G6: edge cases --
+def g6_edges(cp, pm, Cdiag, th0, common):
+    # (a) chain started where logpost = -inf: D = NaN -> min(0, NaN) = 0 -> accepts
+    #     every move until it lands on a finite state (sampler.py:83-84)
+    bad = th0.copy()
+    bad[:, -1] = -0.05  # sig < 0 -> log_prior nan -> -inf
+    bad[2:, -1] = 0.0005  # sig tiny positive: next proposals often cross zero
+    r = run_reference(pm, lambda: scaled_rw(Cdiag, 0.1), bad, seed=6, T=48)
+    save("g6_neginf_start", Cdiag=Cdiag, scale=np.float64(0.1), **common, **r)
+    # (b) Nburn/Nthin slicing and run() continuation (sampler.py:49-54):
+    #     run(10,4,3) then run(5) on the same Sampler
+    r = run_reference(rbench.benchmark_gauss2d_iso, lambda: MetropolisRandomWalk(np.eye(2)),
+                      np.ones((3, 2)), seed=61, T=None, runs=[(10, 4, 3), (5, 0, 1)])
+    save("g6_burn_thin_resume", mu=np.zeros(2), C=np.eye(2), Cprop=np.eye(2),
+         runs=np.array([[10, 4, 3], [5, 0, 1]]), **r)
+
+
+# -------------------------------------------------------- G7: error messages --
+def g7_errors():
+    msgs = {}
+    try:
+        MetropolisRandomWalk(np.eye(3)).propose(np.ones(2))
+    except ParameterError as e:
+        msgs["rw_shape"] = str(e)
+    try:
+        MultiGaussianDist(np.zeros(2), np.ones((2, 3)))
+    except ParameterError as e:
+        msgs["gauss_nonsquare"] = str(e)
+    try:
+        MultiGaussianDist(np.zeros(3), np.eye(2))
+    except ParameterError as e:
+        msgs["gauss_mismatch"] = str(e)
+    save("g7_errors", **{k: np.array(v) for k, v in msgs.items()})
+
+
+if __name__ == "__main__":
+    g0_rng()
+    g1_gauss2d_rw()
+    g2_gauss100d_rw()
+    g3_gauss_hmc()
+    g4_logreg()
+    args = g5_changepoint()
+    g6_edges(*args)
+    g7_errors()

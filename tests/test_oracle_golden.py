@@ -1,0 +1,188 @@
+"""Pins the CPU oracle (oracle/rmh_oracle.c) against the golden vectors that
+tests/golden/make_golden.py recorded from the reference itself.
+
+Bars: accept masks bit-exact; thetas / log-densities within 1e-9 relative of
+the reference's LAPACK-based values (the contract in BASELINE.json is 1e-6;
+the observed agreement is ~1e-13).  CPU only.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = 1e-9
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def replay(z, model, prop, T=None):
+    th = np.ascontiguousarray(z["theta0"]).copy()
+    N = th.shape[0]
+    st = orc.rng_seed(int(z["seed"]), N)
+    lp = model.log_posterior(th)
+    T = T or z["accept"].shape[0]
+    ht, hl, acc = orc.run(model, prop, th, lp, st, T)
+    return ht, hl, acc
+
+
+def check_run(z, ht, hl, acc):
+    np.testing.assert_array_equal(acc, z["accept"])
+    np.testing.assert_allclose(ht, z["thetas"], rtol=RTOL, atol=1e-12)
+    ref = z["logpost"]
+    assert np.array_equal(np.isinf(hl), np.isinf(ref))
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(hl[fin], ref[fin], rtol=RTOL)
+
+
+def corr100():
+    return 0.1 * np.eye(100) + 0.9 * np.ones((100, 100))
+
+
+def test_g0_rng_stream_is_reproduced():
+    z = load("g0_rng")
+    for d in (1, 2, 5, 12, 100):
+        st = orc.rng_seed(int(z["seed"]), 3, chain0=int(z["chain0"]))
+        np.testing.assert_array_equal(st, z["state0_d%d" % d])
+        xi, u = orc.rng_stream(st, d, 3)
+        np.testing.assert_array_equal(xi, z["xi_d%d" % d])
+        np.testing.assert_array_equal(u, z["u_d%d" % d])
+        np.testing.assert_array_equal(st, z["state3_d%d" % d])
+
+
+def test_g1_gauss2d_rw():
+    z = load("g1_gauss2d_rw")
+    xi, u = orc.rng_stream(orc.rng_seed(int(z["seed"]), 4), 2, 64)
+    np.testing.assert_array_equal(xi, z["xi"])
+    np.testing.assert_array_equal(u, z["u"])
+    check_run(z, *replay(z, orc.Gaussian(z["mu"], z["C"]), orc.RandomWalk(z["Cprop"])))
+
+
+def test_g2_gauss100d_rw():
+    z = load("g2_gauss100d_rw")
+    Ct = corr100()
+    check_run(z, *replay(z, orc.Gaussian(z["mu"], Ct), orc.RandomWalk(float(z["prop_factor"]) * Ct)))
+
+
+@pytest.mark.parametrize("tag", ["mala", "hmc10"])
+def test_g3_gauss100d_hmc(tag):
+    z = load("g3_gauss100d_" + tag)
+    check_run(z, *replay(z, orc.Gaussian(np.zeros(100), corr100()),
+                         orc.HMC(float(z["eps"]), int(z["nsteps"]), 100)))
+
+
+def test_g3_gauss2d_hmc5():
+    z = load("g3_gauss2d_hmc5")
+    check_run(z, *replay(z, orc.Gaussian(z["mu"], z["C"]),
+                         orc.HMC(float(z["eps"]), int(z["nsteps"]), 2)))
+
+
+@pytest.mark.parametrize("tag", ["mala", "hmc10"])
+def test_g4_logreg_small(tag):
+    z = load("g4_logreg256x16_" + tag)
+    m = orc.LogReg(z["X"], z["y"], float(z["tau2"]))
+    check_run(z, *replay(z, m, orc.HMC(float(z["eps"]), int(z["nsteps"]), 16)))
+
+
+@pytest.mark.parametrize("tag", ["mala", "hmc10"])
+def test_g4_logreg_full_size(tag):
+    import hashlib
+    from riemann_amd.workloads import logreg_data
+    z = load("g4_logreg10000x100_" + tag)
+    X, y = logreg_data(int(z["n"]), int(z["d"]), int(z["data_seed"]))
+    assert hashlib.sha256(X.tobytes()).digest() == z["X_sha256"].tobytes()
+    assert hashlib.sha256(y.tobytes()).digest() == z["y_sha256"].tobytes()
+    m = orc.LogReg(X, y, float(z["tau2"]))
+    check_run(z, *replay(z, m, orc.HMC(float(z["eps"]), int(z["nsteps"]), 100)))
+
+
+def cp_model(z):
+    return orc.Changepoint(z["x"], z["y"], int(z["k"]), float(z["xmin"]), float(z["xmax"]),
+                           float(z["lamb"]), float(z["alpha"]), float(z["beta"]))
+
+
+@pytest.mark.parametrize("name", ["g5_changepoint_eval", "g5_changepoint_eval_a25"])
+def test_g5_changepoint_eval(name):
+    z = load(name)
+    m = cp_model(z)
+    th = z["theta"]
+    for fn, key in ((m.log_likelihood, "logL"), (m.log_prior, "logP"), (m.log_posterior, "logpost")):
+        got, ref = fn(th), z[key]
+        assert np.array_equal(np.isinf(got), np.isinf(ref)), key
+        assert np.array_equal(np.sign(got[np.isinf(ref)]), np.sign(ref[np.isinf(ref)])), key
+        fin = np.isfinite(ref)
+        np.testing.assert_allclose(got[fin], ref[fin], rtol=RTOL)
+    assert np.isinf(z["logpost"]).sum() >= 12  # the edge rows really are exercised
+    if "idx" in z.files:  # integer path: bit-exact wherever the state is valid
+        ok = np.isfinite(z["logpost"])
+        np.testing.assert_array_equal(m.indices(th)[ok], z["idx"][ok])
+
+
+def test_g5_changepoint_rw():
+    z = load("g5_changepoint_rw")
+    check_run(z, *replay(z, cp_model(z), orc.RandomWalk(np.diag(z["Cdiag"]), float(z["scale"]))))
+
+
+def test_g6_neginf_start_accepts_nan_ratio():
+    z = load("g6_neginf_start")
+    ht, hl, acc = replay(z, cp_model(z), orc.RandomWalk(np.diag(z["Cdiag"]), float(z["scale"])))
+    check_run(z, ht, hl, acc)
+    # chains 0,1 start at -inf and accept their first move (NaN ratio, sampler.py:83-84)
+    assert np.isinf(z["logpost"][0, :2]).all() and z["accept"][0, :2].all()
+
+
+def test_g6_burn_thin_resume():
+    z = load("g6_burn_thin_resume")
+    m, p = orc.Gaussian(z["mu"], z["C"]), orc.RandomWalk(z["Cprop"])
+    th = z["theta0"].copy()
+    st = orc.rng_seed(int(z["seed"]), th.shape[0])
+    lp = m.log_posterior(th)
+    (n0, b0, t0), (n1, b1, t1) = z["runs"]
+    ht, hl, _ = orc.run(m, p, th, lp, st, int(n0))
+    assert z["thetas_run0"].shape[0] == 3  # run(10,4,3) keeps entries 4,7,10
+    np.testing.assert_allclose(ht[b0::t0], z["thetas_run0"], rtol=RTOL)
+    np.testing.assert_allclose(hl[b0::t0], z["logpost_run0"], rtol=RTOL)
+    ht, hl, acc = orc.run(m, p, th, lp, st, int(n1))  # continues from the last state
+    assert z["thetas_run1"].shape[0] == 6
+    np.testing.assert_allclose(ht[b1::t1], z["thetas_run1"], rtol=RTOL)
+    np.testing.assert_array_equal(acc, z["accept_run1"])
+
+
+def test_oracle_math_close_to_libm():
+    g = np.random.default_rng(0)
+    xs = np.concatenate([g.random(2000), 10.0 ** g.uniform(-300, 300, 2000),
+                         [1.0, 2.0 ** -53, 1 - 2.0 ** -53, 5e-324, 2.2e-308]])
+    got = np.array([orc.olog(x) for x in xs])
+    np.testing.assert_allclose(got, np.log(xs), rtol=3e-16, atol=1e-17)
+    assert np.isnan(orc.olog(-1.0)) and orc.olog(0.0) == -np.inf and orc.olog(np.inf) == np.inf
+    us = np.concatenate([g.random(2000), [0.0, 0.125, 0.25, 0.5, 0.75, 1 - 2.0 ** -53]])
+    sc = np.array([orc.sincos2pi(u) for u in us])
+    ang = 2 * np.longdouble("3.14159265358979323846264338327950288") * us.astype(np.longdouble)
+    np.testing.assert_allclose(sc[:, 0], np.sin(ang).astype(np.float64), rtol=0, atol=2.3e-16)
+    np.testing.assert_allclose(sc[:, 1], np.cos(ang).astype(np.float64), rtol=0, atol=2.3e-16)
+
+
+def test_rng_matches_pure_python_restatement():
+    """The stream spec, restated with Python integers and exact rational fma."""
+    from tests.rng_spec import stream_normals_uniform
+    for d in (1, 5, 12):
+        st = orc.rng_seed(99, 2, chain0=3)
+        xi, u = orc.rng_stream(st, d, 2)
+        for c in range(2):
+            exi, eu = stream_normals_uniform(99, 3 + c, d, 2)
+            np.testing.assert_array_equal(xi[:, c], exi)
+            np.testing.assert_array_equal(u[:, c], eu)
+
+
+def test_normals_are_standard_normal():
+    xi, u = orc.rng_stream(orc.rng_seed(7, 4096), 100, 4)
+    assert abs(xi.mean()) < 4 / np.sqrt(xi.size)
+    assert abs(xi.var() - 1) < 0.01
+    assert abs(np.mean(xi ** 4) - 3) < 0.05
+    c = np.corrcoef(xi.reshape(-1, 100), rowvar=False)
+    assert np.abs(c - np.eye(100)).max() < 0.06
+    assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.01

@@ -1,0 +1,145 @@
+/*
+ * riemann_hip.h -- C ABI of libriemann_hip.so, the MI355X (gfx950) back end of
+ * the many-chain Metropolis-Hastings hot path
+ *     Sampler.run() -> Proposal.propose() -> Model.log_posterior()
+ * of rscalzo/riemann.  Plain pointers and sizes only; called from pure Python
+ * through ctypes (riemann_amd/_lib.py) -- the binding a maintainer of the
+ * reference would add is shown in INTEGRATION.md.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative
+ * to the reference repository root).
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on failure;
+ *    rmh_last_error() then describes the failure (thread-local string).
+ *    RMH_ERR_PARAM marks argument/shape errors, which the Python layer raises
+ *    as ParameterError (riemann/sampling_errors.py:23-27, raise sites
+ *    proposals/randomwalk.py:23-24, models/gaussian.py:35-39).
+ *  - host arrays are caller-owned, C-contiguous, borrowed for the call:
+ *    theta is (N, d) float64 row-major as in the reference; device memory is
+ *    library-owned behind the opaque handles and released by the *_free calls.
+ *  - non-finite log densities are data, not errors: they follow
+ *    Model.log_posterior (models/model.py:49-52: nan or +-inf -> -inf) and the
+ *    accept rule of Sampler.sample (samplers/sampler.py:83-84).
+ *  - one device per process (rmh_init); handles are not thread-safe.
+ *  - random numbers: the "rmh-rng v1" stream, keyed by
+ *    (seed, GLOBAL chain id); it replaces the process-global np.random used at
+ *    proposals/randomwalk.py:25, proposals/hamiltonian.py:79, samplers/sampler.py:84.
+ */
+#ifndef RIEMANN_HIP_H
+#define RIEMANN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMH_OK 0
+#define RMH_ERR_PARAM 1   /* bad argument / shape: ParameterError */
+#define RMH_ERR_HIP 2     /* HIP runtime failure: RuntimeError */
+#define RMH_ERR_STATE 3   /* call out of sequence (e.g. empty history) */
+
+typedef struct rmh_model *rmh_model_t;
+typedef struct rmh_proposal *rmh_proposal_t;
+typedef struct rmh_state *rmh_state_t;
+typedef struct rmh_history *rmh_history_t;
+
+/* ---- context ------------------------------------------------------------ */
+int rmh_init(int device);                 /* hipSetDevice + stream; idempotent */
+int rmh_device_count(int *count);
+int rmh_device_name(char *buf, int buflen);
+int rmh_synchronize(void);                /* drain the library's stream */
+const char *rmh_last_error(void);
+/* duration in ms (HIP events on the library's stream) of the kernels of the
+ * last rmh_run call, and their number */
+int rmh_last_run_ms(double *ms, int *launches);
+
+/* ---- Model: riemann/models/model.py:4-64 -------------------------------- */
+/* MultiGaussianDist(mu, C), models/gaussian.py:27-44.  L = cholesky(C), lower,
+ * (d,d) row-major, as gaussian.py:42 caches it. */
+int rmh_model_gaussian_create(const double *mu, const double *L, int d, rmh_model_t *out);
+/* Logistic regression with N(0, tau2 I) prior -- a new plugin against the
+ * Model ABC (not in the reference; spec in DESIGN.md).  X (n,d) row-major, y (n). */
+int rmh_model_logreg_create(const double *X, const double *y, int64_t n, int d,
+                            double tau2, rmh_model_t *out);
+/* ChangepointRegression1D at fixed k, models/changepoint.py:86-181.
+ * theta packs (cpx[k], cpv[k+1], sig): d = 2k+2. */
+int rmh_model_changepoint_create(const double *x, const double *y, int n, int k,
+                                 double xmin, double xmax, double lamb,
+                                 double alpha, double beta, rmh_model_t *out);
+int rmh_model_dim(rmh_model_t m, int *d);
+int rmh_model_free(rmh_model_t m);
+
+/* Model.log_prior / log_likelihood / log_posterior (models/model.py:27-55) and
+ * the gradient contract of hamiltonian.py:60-70, for N states at once.
+ * theta (N,d) -> out (N) or (N,d).  Host in, host out. */
+int rmh_log_prior(rmh_model_t m, const double *theta, int64_t N, double *out);
+int rmh_log_likelihood(rmh_model_t m, const double *theta, int64_t N, double *out);
+int rmh_log_posterior(rmh_model_t m, const double *theta, int64_t N, double *out);
+int rmh_grad_log_posterior(rmh_model_t m, const double *theta, int64_t N, double *out);
+
+/* ---- Proposal: riemann/proposals/proposal.py:1-26 ----------------------- */
+/* MetropolisRandomWalk(C), proposals/randomwalk.py:17-26.  L = cholesky(C). */
+int rmh_proposal_rw_create(const double *L, int d, double scale, rmh_proposal_t *out);
+/* VanillaHMC(eps, Nsteps, gradlogpost, M=None), proposals/hamiltonian.py:60-91;
+ * the gradient is the device Model's.  Nsteps = 1 is MALA. */
+int rmh_proposal_hmc_create(double eps, int nsteps, int d, rmh_proposal_t *out);
+int rmh_proposal_set_scale(rmh_proposal_t p, double scale); /* .scale, randomwalk.py:18 */
+int rmh_proposal_set_eps(rmh_proposal_t p, double eps);     /* .eps, hamiltonian.py:69 */
+int rmh_proposal_free(rmh_proposal_t p);
+
+/* Proposal.propose (proposal.py:10-17) for N states: theta (N,d) ->
+ * theta_p (N,d), logqratio (N).  rng (N,16) uint64 is advanced in place. */
+int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
+                uint64_t *rng, double *theta_p, double *logq);
+
+/* ---- chain state (device resident; survives between run() calls as the
+ *      history lists do, samplers/sampler.py:49-50) ------------------------ */
+/* N chains with global ids chain0 .. chain0+N-1 and streams seeded from `seed`. */
+int rmh_state_create(rmh_model_t m, int64_t N, uint64_t seed, uint64_t chain0,
+                     rmh_state_t *out);
+/* Sampler.__init__, sampler.py:34-42: store theta0 and evaluate log_posterior. */
+int rmh_state_set_theta(rmh_state_t s, const double *theta);
+int rmh_state_get(rmh_state_t s, double *theta, double *logpost); /* current_state(), :56-60 */
+int rmh_state_get_rng(rmh_state_t s, uint64_t *rng);   /* (N,16) */
+int rmh_state_set_rng(rmh_state_t s, const uint64_t *rng);
+int rmh_state_device_ptrs(rmh_state_t s, void **theta_dn, void **logpost,
+                          int64_t *ld);                 /* theta is (d, ld) on device */
+int rmh_state_free(rmh_state_t s);
+
+/* ---- history (device resident) ------------------------------------------ */
+/* room for `entries` kept states and `iters` accept flags per chain */
+int rmh_history_create(rmh_state_t s, int64_t entries, int64_t iters, rmh_history_t *out);
+int rmh_history_entries(rmh_history_t h, int64_t *entries, int64_t *iters);
+/* entries [e0,e1) -> thetas (e1-e0, N, d), logpost (e1-e0, N); either may be NULL */
+int rmh_history_download(rmh_history_t h, int64_t e0, int64_t e1, double *thetas,
+                         double *logpost);
+/* accept flags of iterations [t0,t1) -> (t1-t0, N) uint8 */
+int rmh_history_accept(rmh_history_t h, int64_t t0, int64_t t1, uint8_t *accept);
+int rmh_history_device_ptrs(rmh_history_t h, void **thetas_edn, void **logpost_en,
+                            void **accept_tn, int64_t *ld);
+int rmh_history_free(rmh_history_t h);
+
+/* ---- Sampler.run(Nsamples, Nburn, Nthin): samplers/sampler.py:44-54 ------
+ * Runs T = Nsamples fused iterations of Sampler.sample (sampler.py:72-90) for
+ * every chain of `s`.  The T+1 states (state on entry, then one per iteration)
+ * are numbered e = 0..T; e is kept iff e >= nburn and (e-nburn) % nthin == 0
+ * (the slice [Nburn::Nthin] of sampler.py:53-54) and written to history entry
+ * (e-nburn)/nthin when `h` is not NULL.  As in the reference the chain's
+ * current state afterwards is the LAST KEPT entry. */
+int rmh_run(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t nburn,
+            int64_t nthin, rmh_history_t h);
+
+/* ---- test hooks ---------------------------------------------------------- */
+/* the stream as the reference consumes it: xi (T,N,d), u (T,N) for chains
+ * chain0..chain0+N-1, generated on the device */
+int rmh_debug_rng_stream(uint64_t seed, uint64_t chain0, int64_t N, int d, int T,
+                         double *xi, double *u);
+/* D = A(16x4) B(4x16) + C(16x16) through one v_mfma_f64_16x16x4_f64, row-major in/out */
+int rmh_debug_mfma(const double *A, const double *B, const double *C, double *D);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIEMANN_HIP_H */

@@ -1,0 +1,105 @@
+"""ctypes binding of csrc/libriemann_hip.so (C ABI: include/riemann_hip.h).
+
+There is no CPU implementation behind this module: if the library has not
+been built, or no MI355X is visible when a compute entry point is called, the
+call raises.  Build with ``python -m riemann_amd.build`` (hipcc, gfx950).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .sampling_errors import ParameterError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libriemann_hip.so")
+
+RMH_OK, RMH_ERR_PARAM, RMH_ERR_HIP, RMH_ERR_STATE = 0, 1, 2, 3
+
+_f64 = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_u64 = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+_u8 = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_vp, _i64, _u64s, _dbl, _int = C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_int
+_pvp = C.POINTER(C.c_void_p)
+
+# name -> argtypes; every function returns int except rmh_last_error
+SIGNATURES = {
+    "rmh_init": [_int],
+    "rmh_device_count": [C.POINTER(_int)],
+    "rmh_device_name": [C.c_char_p, _int],
+    "rmh_synchronize": [],
+    "rmh_last_run_ms": [C.POINTER(_dbl), C.POINTER(_int)],
+    "rmh_model_gaussian_create": [_f64, _f64, _int, _pvp],
+    "rmh_model_logreg_create": [_f64, _f64, _i64, _int, _dbl, _pvp],
+    "rmh_model_changepoint_create": [_f64, _f64, _int, _int, _dbl, _dbl, _dbl, _dbl, _dbl, _pvp],
+    "rmh_model_dim": [_vp, C.POINTER(_int)],
+    "rmh_model_free": [_vp],
+    "rmh_log_prior": [_vp, _f64, _i64, _f64],
+    "rmh_log_likelihood": [_vp, _f64, _i64, _f64],
+    "rmh_log_posterior": [_vp, _f64, _i64, _f64],
+    "rmh_grad_log_posterior": [_vp, _f64, _i64, _f64],
+    "rmh_proposal_rw_create": [_f64, _int, _dbl, _pvp],
+    "rmh_proposal_hmc_create": [_dbl, _int, _int, _pvp],
+    "rmh_proposal_set_scale": [_vp, _dbl],
+    "rmh_proposal_set_eps": [_vp, _dbl],
+    "rmh_proposal_free": [_vp],
+    "rmh_propose": [_vp, _vp, _f64, _i64, _u64, _f64, _f64],
+    "rmh_state_create": [_vp, _i64, _u64s, _u64s, _pvp],
+    "rmh_state_set_theta": [_vp, _f64],
+    "rmh_state_get": [_vp, _vp, _vp],
+    "rmh_state_get_rng": [_vp, _u64],
+    "rmh_state_set_rng": [_vp, _u64],
+    "rmh_state_device_ptrs": [_vp, _pvp, _pvp, C.POINTER(_i64)],
+    "rmh_state_free": [_vp],
+    "rmh_history_create": [_vp, _i64, _i64, _pvp],
+    "rmh_history_entries": [_vp, C.POINTER(_i64), C.POINTER(_i64)],
+    "rmh_history_download": [_vp, _i64, _i64, _vp, _vp],
+    "rmh_history_accept": [_vp, _i64, _i64, _u8],
+    "rmh_history_device_ptrs": [_vp, _pvp, _pvp, _pvp, C.POINTER(_i64)],
+    "rmh_history_free": [_vp],
+    "rmh_run": [_vp, _vp, _vp, _i64, _i64, _i64, _vp],
+    "rmh_debug_rng_stream": [_u64s, _u64s, _i64, _int, _int, _f64, _f64],
+    "rmh_debug_mfma": [_f64, _f64, _f64, _f64],
+}
+
+_lib = None
+
+
+def load():
+    """The CDLL, loaded once.  Loading needs no GPU; calling compute entries does."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            "riemann_amd: %s is missing -- build it with `python -m riemann_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+    lib = C.CDLL(SO_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _int
+    lib.rmh_last_error.argtypes = []
+    lib.rmh_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Map a C-ABI return code to the exceptions of the plugin API."""
+    if rc == RMH_OK:
+        return
+    msg = load().rmh_last_error().decode("utf-8", "replace")
+    if rc == RMH_ERR_PARAM:
+        raise ParameterError(msg)  # riemann/proposals/randomwalk.py:23-24, models/gaussian.py:35-39
+    if rc == RMH_ERR_STATE:
+        raise IndexError(msg)      # e.g. current_state() of an empty history, sampler.py:60
+    raise RuntimeError("riemann_amd (HIP): " + msg)
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

@@ -1,0 +1,49 @@
+"""Builds riemann_amd/csrc/libriemann_hip.so with hipcc for gfx950 (in-tree).
+
+    python -m riemann_amd.build            # build if sources are newer
+    python -m riemann_amd.build --force
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off: the random stream is
+specified operation by operation (explicit fma), see csrc/rmh_device.hpp.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(CSRC, "libriemann_hip.so")
+SOURCES = ["rmh_api.hip", "rmh_kernels_mfma.hip", "rmh_kernels_cp.hip"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _newest_source():
+    names = [f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    names.append(os.path.join("..", "..", "include", "riemann_hip.h"))
+    return max(os.path.getmtime(os.path.join(CSRC, f)) for f in names)
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(SO) and os.path.getmtime(SO) >= _newest_source():
+        return SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+
+    def compile_one(src):
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

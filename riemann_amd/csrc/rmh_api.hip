@@ -1,0 +1,961 @@
+// rmh_api.hip -- the C ABI of libriemann_hip.so (include/riemann_hip.h): host
+// side of the MI355X back end.  Owns the device buffers behind the opaque
+// handles, packs host operands into the kernels' tile images and launches the
+// kernels of rmh_kernels_*.hip on the library's stream.  No computation of the
+// hot path happens on the host: a missing GPU is an error, never a fallback.
+#include "../../include/riemann_hip.h"
+#include "rmh_internal.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+using namespace rmh;
+
+// ------------------------------------------------------------------ context
+namespace {
+
+thread_local std::string g_err;
+bool g_init = false;
+int g_device = -1;
+hipStream_t g_stream = nullptr;
+hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+int g_last_launches = 0;
+bool g_timed = false;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define RMH_HIP(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(RMH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define RMH_NEED_INIT()                                                                  \
+    do {                                                                                 \
+        if (!g_init) {                                                                   \
+            int rc_ = rmh_init(0);                                                       \
+            if (rc_) return rc_;                                                         \
+        }                                                                                \
+    } while (0)
+
+template <class T>
+int dev_alloc(T **p, size_t n)
+{
+    *p = nullptr;
+    if (n == 0) return RMH_OK;
+    RMH_HIP(hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)));
+    return RMH_OK;
+}
+
+template <class T>
+int upload(T **p, const T *h, size_t n)
+{
+    int rc = dev_alloc(p, n);
+    if (rc) return rc;
+    RMH_HIP(hipMemcpy(*p, h, n * sizeof(T), hipMemcpyHostToDevice));
+    return RMH_OK;
+}
+
+int64_t pad16(int64_t n) { return (n + 15) / 16 * 16; }
+
+// tile (i, s) of a (d x d) row-major matrix in A-operand lane order, scaled
+void pack_tile(const double *M, int d, int i, int s, double scale, bool transpose, double *out)
+{
+    for (int l = 0; l < 64; ++l) {
+        const int row = 16 * i + (l & 15), col = 4 * s + (l >> 4);
+        double v = 0.0;
+        if (row < d && col < d) v = transpose ? M[col * d + row] : M[row * d + col];
+        out[l] = scale * v;
+    }
+}
+
+// lower-triangular image: tiles (i, s), s <= 4i+3, index 2i(i+1)+s
+std::vector<double> pack_lower(const double *M, int d, int NT, double scale)
+{
+    std::vector<double> img((size_t)tri_tiles(NT) * 64, 0.0);
+    for (int i = 0; i < NT; ++i)
+        for (int s = 0; s < 4 * (i + 1); ++s)
+            pack_tile(M, d, i, s, scale, false, &img[(size_t)(2 * i * (i + 1) + s) * 64]);
+    return img;
+}
+
+// upper-triangular image of M^T (M lower): tiles (i, s), s >= 4i
+std::vector<double> pack_upper_T(const double *M, int d, int NT)
+{
+    const int S = 4 * NT;
+    std::vector<double> img((size_t)tri_tiles(NT) * 64, 0.0);
+    for (int i = 0; i < NT; ++i)
+        for (int s = 4 * i; s < S; ++s)
+            pack_tile(M, d, i, s, 1.0, true, &img[(size_t)(i * S - 2 * i * (i - 1) + (s - 4 * i)) * 64]);
+    return img;
+}
+
+bool lower_ok(const double *L, int d)
+{
+    for (int i = 0; i < d; ++i) {
+        if (!(L[i * d + i] > 0.0) || !std::isfinite(L[i * d + i])) return false;
+        for (int j = i + 1; j < d; ++j)
+            if (L[i * d + j] != 0.0) return false;
+    }
+    return true;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ handles
+struct rmh_model {
+    int kind = 0, d = 0, NT = 0;
+    // gaussian
+    double *d_W = nullptr, *d_WT = nullptr, *d_mu = nullptr;
+    GaussArgs ga{};
+    // logreg
+    double *d_X = nullptr;
+    LogRegArgs la{};
+    // changepoint
+    int k = 0;
+    double *d_xy = nullptr;
+    CpArgs ca{};
+};
+
+struct rmh_proposal {
+    int kind = 0, d = 0, NT = 0;
+    double scale = 1.0, eps = 0.0;
+    int nsteps = 0;
+    std::vector<double> L;     // host copy of the Cholesky factor
+    double *d_Ltiles = nullptr;
+    bool dirty = true;
+};
+
+struct rmh_state {
+    rmh_model *m = nullptr;
+    int64_t N = 0, ld = 0;
+    int d = 0, dp = 0, ks = 0, NT = 0;
+    double *theta = nullptr, *grad = nullptr, *logpost = nullptr;
+    uint64_t *rng = nullptr;
+    bool valid = false, grad_valid = false;
+};
+
+struct rmh_history {
+    rmh_state *s = nullptr;
+    int64_t entries = 0, iters = 0;
+    double *thetas = nullptr, *logpost = nullptr;
+    uint8_t *accept = nullptr;
+};
+
+namespace {
+
+ChainArgs chain_args(const rmh_state *s)
+{
+    ChainArgs c{};
+    c.theta = s->theta;
+    c.logpost = s->logpost;
+    c.grad = s->grad;
+    c.rng = s->rng;
+    c.ld = s->ld;
+    c.nslots = 4 * s->ld;
+    c.nblocks = s->ld / 16;
+    c.d = s->d;
+    c.dp = s->dp;
+    c.ks = s->ks;
+    c.P = ((s->d + 3) / 4 + 1) / 2;
+    return c;
+}
+
+int sync_proposal(rmh_proposal *p)
+{
+    if (p->kind != kRW || !p->dirty) return RMH_OK;
+    std::vector<double> img = pack_lower(p->L.data(), p->d, p->NT, p->scale);
+    if (!p->d_Ltiles) {
+        int rc = dev_alloc(&p->d_Ltiles, img.size());
+        if (rc) return rc;
+    }
+    RMH_HIP(hipMemcpy(p->d_Ltiles, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
+    p->dirty = false;
+    return RMH_OK;
+}
+
+// log posterior (and optionally gradient / parts) of the states in `c`
+int eval_states(rmh_model *m, const ChainArgs &c, bool want_grad, double *lp, double *grad,
+                double *lprior, double *llik)
+{
+    hipError_t e = hipSuccess;
+    switch (m->kind) {
+    case kGauss:
+        e = launch_gauss_eval(m->NT, m->ga, c, want_grad, lp, grad, lprior, llik, g_stream);
+        break;
+    case kLogReg:
+        e = launch_logreg_eval(m->NT, m->la, c, want_grad, lp, grad, lprior, llik, g_stream);
+        break;
+    case kChangepoint:
+        if (want_grad)
+            return fail(RMH_ERR_PARAM, "the changepoint model has no gradient "
+                                       "(riemann/models/changepoint.py:108-113)");
+        e = launch_cp_eval(m->k, m->ca, c, lprior, llik, lp, g_stream);
+        break;
+    default:
+        return fail(RMH_ERR_PARAM, "unknown model kind");
+    }
+    RMH_HIP(e);
+    return RMH_OK;
+}
+
+int ensure_grad(rmh_state *s)
+{
+    if (s->grad_valid) return RMH_OK;
+    if (!s->grad) {
+        int rc = dev_alloc(&s->grad, (size_t)s->dp * s->ld);
+        if (rc) return rc;
+        RMH_HIP(hipMemsetAsync(s->grad, 0, (size_t)s->dp * s->ld * sizeof(double), g_stream));
+    }
+    ChainArgs c = chain_args(s);
+    int rc = eval_states(s->m, c, true, nullptr, s->grad, nullptr, nullptr);
+    if (rc) return rc;
+    s->grad_valid = true;
+    return RMH_OK;
+}
+
+// temporary device state for the host-in/host-out entry points
+struct TmpState {
+    rmh_state s;
+    double *staging = nullptr;
+    ~TmpState()
+    {
+        (void)hipFree(s.theta);
+        (void)hipFree(s.grad);
+        (void)hipFree(s.logpost);
+        (void)hipFree(s.rng);
+        (void)hipFree(staging);
+    }
+};
+
+int tmp_state(TmpState &t, rmh_model *m, const double *theta, int64_t N)
+{
+    rmh_state &s = t.s;
+    s.m = m;
+    s.N = N;
+    s.ld = pad16(N);
+    s.d = m->d;
+    s.NT = m->NT;
+    s.dp = 16 * m->NT;
+    s.ks = (m->d + 3) / 4;
+    int rc;
+    if ((rc = dev_alloc(&s.theta, (size_t)s.dp * s.ld))) return rc;
+    if ((rc = dev_alloc(&s.logpost, (size_t)s.ld))) return rc;
+    if ((rc = upload(&t.staging, theta, (size_t)N * s.d))) return rc;
+    RMH_HIP(hipMemsetAsync(s.theta, 0, (size_t)s.dp * s.ld * sizeof(double), g_stream));
+    RMH_HIP(launch_transpose_nd_to_dn(t.staging, s.theta, N, s.d, s.ld, g_stream));
+    return RMH_OK;
+}
+
+void rng_to_device_layout(const uint64_t *host, int64_t N, int64_t ld, std::vector<uint64_t> &dev)
+{
+    const int64_t nslots = 4 * ld;
+    dev.assign((size_t)4 * nslots, 0);
+    for (int64_t c = 0; c < N; ++c)
+        for (int g = 0; g < 4; ++g) {
+            const int64_t slot = (c >> 4) * 64 + g * 16 + (c & 15);
+            for (int w = 0; w < 4; ++w) dev[(size_t)w * nslots + slot] = host[c * 16 + g * 4 + w];
+        }
+}
+
+void rng_from_device_layout(const std::vector<uint64_t> &dev, int64_t N, int64_t ld, uint64_t *host)
+{
+    const int64_t nslots = 4 * ld;
+    for (int64_t c = 0; c < N; ++c)
+        for (int g = 0; g < 4; ++g) {
+            const int64_t slot = (c >> 4) * 64 + g * 16 + (c & 15);
+            for (int w = 0; w < 4; ++w) host[c * 16 + g * 4 + w] = dev[(size_t)w * nslots + slot];
+        }
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ context
+extern "C" {
+
+const char *rmh_last_error(void) { return g_err.c_str(); }
+
+int rmh_device_count(int *count)
+{
+    RMH_HIP(hipGetDeviceCount(count));
+    return RMH_OK;
+}
+
+int rmh_init(int device)
+{
+    if (g_init && device == g_device) return RMH_OK;
+    if (g_init) return fail(RMH_ERR_STATE, "rmh_init: already bound to another device");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(RMH_ERR_HIP, "rmh_init: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(RMH_ERR_PARAM, "rmh_init: bad device index");
+    RMH_HIP(hipSetDevice(device));
+    RMH_HIP(hipStreamCreate(&g_stream));
+    RMH_HIP(hipEventCreate(&g_ev0));
+    RMH_HIP(hipEventCreate(&g_ev1));
+    g_device = device;
+    g_init = true;
+    return RMH_OK;
+}
+
+int rmh_device_name(char *buf, int buflen)
+{
+    RMH_NEED_INIT();
+    hipDeviceProp_t prop;
+    RMH_HIP(hipGetDeviceProperties(&prop, g_device));
+    snprintf(buf, (size_t)buflen, "%s %s", prop.name, prop.gcnArchName);
+    return RMH_OK;
+}
+
+int rmh_synchronize(void)
+{
+    RMH_NEED_INIT();
+    RMH_HIP(hipStreamSynchronize(g_stream));
+    return RMH_OK;
+}
+
+int rmh_last_run_ms(double *ms, int *launches)
+{
+    RMH_NEED_INIT();
+    if (!g_timed) return fail(RMH_ERR_STATE, "rmh_last_run_ms: no run recorded");
+    RMH_HIP(hipEventSynchronize(g_ev1));
+    float f = 0.f;
+    RMH_HIP(hipEventElapsedTime(&f, g_ev0, g_ev1));
+    if (ms) *ms = f;
+    if (launches) *launches = g_last_launches;
+    return RMH_OK;
+}
+
+// ------------------------------------------------------------------- models
+int rmh_model_gaussian_create(const double *mu, const double *L, int d, rmh_model_t *out)
+{
+    RMH_NEED_INIT();
+    if (d < 1) return fail(RMH_ERR_PARAM, "gaussian: d must be >= 1");
+    const int NT = nt_for_dim(d);
+    if (NT < 0) return fail(RMH_ERR_PARAM, "gaussian: d > 112 is not supported by the MFMA tile yet");
+    if (!lower_ok(L, d))
+        return fail(RMH_ERR_PARAM, "gaussian: L must be a lower-triangular Cholesky factor");
+    // W = L^-1 by forward substitution (columns of the identity)
+    std::vector<double> W((size_t)d * d, 0.0);
+    for (int col = 0; col < d; ++col)
+        for (int i = col; i < d; ++i) {
+            double acc = (i == col) ? 1.0 : 0.0;
+            for (int j = col; j < i; ++j) acc -= L[i * d + j] * W[j * d + col];
+            W[i * d + col] = acc / L[i * d + i];
+        }
+    double slog = 0.0;
+    for (int i = 0; i < d; ++i) slog += std::log(L[i * d + i]);
+    rmh_model *m = new rmh_model;
+    m->kind = kGauss;
+    m->d = d;
+    m->NT = NT;
+    std::vector<double> lo = pack_lower(W.data(), d, NT, 1.0), up = pack_upper_T(W.data(), d, NT);
+    std::vector<double> mup((size_t)16 * NT, 0.0);
+    for (int i = 0; i < d; ++i) mup[i] = mu[i];
+    int rc;
+    if ((rc = upload(&m->d_W, lo.data(), lo.size())) || (rc = upload(&m->d_WT, up.data(), up.size())) ||
+        (rc = upload(&m->d_mu, mup.data(), mup.size()))) {
+        rmh_model_free(m);
+        return rc;
+    }
+    m->ga.Wtiles = m->d_W;
+    m->ga.WTtiles = m->d_WT;
+    m->ga.mu_pad = m->d_mu;
+    m->ga.dlog2pi = d * std::log(2 * M_PI);   // gaussian.py:52
+    m->ga.logdetC = 2 * slog;                 // gaussian.py:43
+    *out = m;
+    return RMH_OK;
+}
+
+int rmh_model_logreg_create(const double *X, const double *y, int64_t n, int d, double tau2,
+                            rmh_model_t *out)
+{
+    RMH_NEED_INIT();
+    if (d < 1 || n < 1) return fail(RMH_ERR_PARAM, "logreg: need n >= 1 rows and d >= 1 columns");
+    if (!(tau2 > 0)) return fail(RMH_ERR_PARAM, "logreg: tau2 must be positive");
+    const int NT = nt_for_dim(d);
+    if (NT < 0) return fail(RMH_ERR_PARAM, "logreg: d > 112 is not supported by the MFMA tile yet");
+    const int64_t nrt = (n + 15) / 16;
+    const int RT = 4 * NT * 64 + 32;
+    std::vector<double> img((size_t)nrt * RT, 0.0);
+    for (int64_t rt = 0; rt < nrt; ++rt) {
+        double *t = &img[(size_t)rt * RT];
+        for (int i = 0; i < 16; ++i) {
+            const int64_t row = rt * 16 + i;
+            if (row >= n) continue;
+            for (int k = 0; k < d; ++k) {
+                const int s = k >> 2, gg = k & 3;
+                const int F = ((s & 3) << 2) | ((gg >> 1) << 1);
+                t[s * 64 + gg * 16 + (i ^ F)] = X[row * d + k];
+            }
+            t[4 * NT * 64 + i] = y[row];
+            t[4 * NT * 64 + 16 + i] = 1.0;
+        }
+    }
+    rmh_model *m = new rmh_model;
+    m->kind = kLogReg;
+    m->d = d;
+    m->NT = NT;
+    int rc = upload(&m->d_X, img.data(), img.size());
+    if (rc) {
+        rmh_model_free(m);
+        return rc;
+    }
+    m->la.Ximg = m->d_X;
+    m->la.yw = nullptr;
+    m->la.nrt = nrt;
+    m->la.inv_tau2 = 1.0 / tau2;
+    m->la.two_tau2 = 2.0 * tau2;
+    *out = m;
+    return RMH_OK;
+}
+
+int rmh_model_changepoint_create(const double *x, const double *y, int n, int k, double xmin,
+                                 double xmax, double lamb, double alpha, double beta,
+                                 rmh_model_t *out)
+{
+    RMH_NEED_INIT();
+    if (k < 1 || k > 8) return fail(RMH_ERR_PARAM, "changepoint: 1 <= k <= 8 changepoints supported");
+    if (n < 1 || n > 8192) return fail(RMH_ERR_PARAM, "changepoint: 1 <= n <= 8192 data points supported");
+    rmh_model *m = new rmh_model;
+    m->kind = kChangepoint;
+    m->k = k;
+    m->d = 2 * k + 2;
+    m->NT = nt_for_dim(m->d);
+    std::vector<double> xy((size_t)2 * n);
+    for (int i = 0; i < n; ++i) {
+        xy[i] = x[i];
+        xy[n + i] = y[i];
+    }
+    int rc = upload(&m->d_xy, xy.data(), xy.size());
+    if (rc) {
+        rmh_model_free(m);
+        return rc;
+    }
+    const double kp = k + 1; // "k = len(theta.cpv)", changepoint.py:133
+    CpArgs &a = m->ca;
+    a.xy = m->d_xy;
+    a.n = n;
+    a.xmin = xmin;
+    a.xmax = xmax;
+    a.alpha_m1 = alpha - 1;
+    a.beta = beta;
+    a.c_k = kp * std::log(lamb) - std::lgamma(kp) - lamb; // :134
+    a.c_v = alpha * std::log(beta);                       // :19
+    a.lgam_alpha = std::lgamma(alpha);
+    a.c_s = std::lgamma(2 * kp + 1);                      // :143
+    a.c_sL = kp * std::log(xmax - xmin);
+    a.nlog2pi = n * std::log(2 * M_PI);                   // :119
+    *out = m;
+    return RMH_OK;
+}
+
+int rmh_model_dim(rmh_model_t m, int *d)
+{
+    if (!m) return fail(RMH_ERR_PARAM, "null model");
+    *d = m->d;
+    return RMH_OK;
+}
+
+int rmh_model_free(rmh_model_t m)
+{
+    if (!m) return RMH_OK;
+    (void)hipFree(m->d_W);
+    (void)hipFree(m->d_WT);
+    (void)hipFree(m->d_mu);
+    (void)hipFree(m->d_X);
+    (void)hipFree(m->d_xy);
+    delete m;
+    return RMH_OK;
+}
+
+static int eval_host(rmh_model_t m, const double *theta, int64_t N, int which, double *out)
+{
+    RMH_NEED_INIT();
+    if (!m || !theta || !out || N < 1) return fail(RMH_ERR_PARAM, "bad argument");
+    TmpState t;
+    int rc = tmp_state(t, m, theta, N);
+    if (rc) return rc;
+    ChainArgs c = chain_args(&t.s);
+    if (which == 3) { // gradient
+        if ((rc = dev_alloc(&t.s.grad, (size_t)t.s.dp * t.s.ld))) return rc;
+        RMH_HIP(hipMemsetAsync(t.s.grad, 0, (size_t)t.s.dp * t.s.ld * sizeof(double), g_stream));
+        if ((rc = eval_states(m, c, true, nullptr, t.s.grad, nullptr, nullptr))) return rc;
+        double *nd = nullptr;
+        if ((rc = dev_alloc(&nd, (size_t)N * m->d))) return rc;
+        hipError_t e = launch_transpose_dn_to_nd(t.s.grad, nd, N, m->d, t.s.ld, 1, g_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out, nd, (size_t)N * m->d * sizeof(double), hipMemcpyDeviceToHost, g_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        (void)hipFree(nd);
+        RMH_HIP(e);
+        return RMH_OK;
+    }
+    double *lp = t.s.logpost;
+    rc = eval_states(m, c, false, which == 2 ? lp : nullptr, nullptr, which == 0 ? lp : nullptr,
+                     which == 1 ? lp : nullptr);
+    if (rc) return rc;
+    RMH_HIP(hipMemcpyAsync(out, lp, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    RMH_HIP(hipStreamSynchronize(g_stream));
+    return RMH_OK;
+}
+
+int rmh_log_prior(rmh_model_t m, const double *theta, int64_t N, double *out) { return eval_host(m, theta, N, 0, out); }
+int rmh_log_likelihood(rmh_model_t m, const double *theta, int64_t N, double *out) { return eval_host(m, theta, N, 1, out); }
+int rmh_log_posterior(rmh_model_t m, const double *theta, int64_t N, double *out) { return eval_host(m, theta, N, 2, out); }
+int rmh_grad_log_posterior(rmh_model_t m, const double *theta, int64_t N, double *out) { return eval_host(m, theta, N, 3, out); }
+
+// ---------------------------------------------------------------- proposals
+int rmh_proposal_rw_create(const double *L, int d, double scale, rmh_proposal_t *out)
+{
+    RMH_NEED_INIT();
+    if (d < 1) return fail(RMH_ERR_PARAM, "random walk: d must be >= 1");
+    const int NT = nt_for_dim(d);
+    if (NT < 0) return fail(RMH_ERR_PARAM, "random walk: d > 112 is not supported by the MFMA tile yet");
+    if (!lower_ok(L, d))
+        return fail(RMH_ERR_PARAM, "random walk: L must be a lower-triangular Cholesky factor");
+    rmh_proposal *p = new rmh_proposal;
+    p->kind = kRW;
+    p->d = d;
+    p->NT = NT;
+    p->scale = scale;
+    p->L.assign(L, L + (size_t)d * d);
+    p->dirty = true;
+    *out = p;
+    return RMH_OK;
+}
+
+int rmh_proposal_hmc_create(double eps, int nsteps, int d, rmh_proposal_t *out)
+{
+    RMH_NEED_INIT();
+    if (d < 1) return fail(RMH_ERR_PARAM, "hmc: d must be >= 1");
+    if (nsteps < 1) return fail(RMH_ERR_PARAM, "hmc: Nsteps must be an integer >= 1 (hamiltonian.py:64)");
+    rmh_proposal *p = new rmh_proposal;
+    p->kind = kHMC;
+    p->d = d;
+    p->NT = nt_for_dim(d);
+    p->eps = eps;
+    p->nsteps = nsteps;
+    *out = p;
+    return RMH_OK;
+}
+
+int rmh_proposal_set_scale(rmh_proposal_t p, double scale)
+{
+    if (!p) return fail(RMH_ERR_PARAM, "null proposal");
+    if (p->scale != scale) {
+        p->scale = scale;
+        p->dirty = true;
+    }
+    return RMH_OK;
+}
+
+int rmh_proposal_set_eps(rmh_proposal_t p, double eps)
+{
+    if (!p) return fail(RMH_ERR_PARAM, "null proposal");
+    p->eps = eps;
+    return RMH_OK;
+}
+
+int rmh_proposal_free(rmh_proposal_t p)
+{
+    if (!p) return RMH_OK;
+    (void)hipFree(p->d_Ltiles);
+    delete p;
+    return RMH_OK;
+}
+
+int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N, uint64_t *rng,
+                double *theta_p, double *logq)
+{
+    RMH_NEED_INIT();
+    if (!p || !theta || !rng || !theta_p || !logq || N < 1) return fail(RMH_ERR_PARAM, "bad argument");
+    if (p->kind == kHMC && !m) return fail(RMH_ERR_PARAM, "hmc: needs a device Model for the gradient");
+    if (m && m->d != p->d)
+        return fail(RMH_ERR_PARAM, "theta and L have incompatible shapes"); // randomwalk.py:24
+    // a model-less random walk borrows a dimension-only stand-in
+    rmh_model shape;
+    shape.d = p->d;
+    shape.NT = p->NT;
+    TmpState t;
+    int rc = tmp_state(t, m ? m : &shape, theta, N);
+    if (rc) return rc;
+    rmh_state &s = t.s;
+    std::vector<uint64_t> dev;
+    rng_to_device_layout(rng, N, s.ld, dev);
+    if ((rc = upload(&s.rng, dev.data(), dev.size()))) return rc;
+    double *outp = nullptr, *lq = nullptr, *nd = nullptr;
+    if ((rc = dev_alloc(&outp, (size_t)s.dp * s.ld)) || (rc = dev_alloc(&lq, (size_t)s.ld)) ||
+        (rc = dev_alloc(&nd, (size_t)N * s.d))) {
+        (void)hipFree(outp); (void)hipFree(lq); (void)hipFree(nd);
+        return rc;
+    }
+    ChainArgs c = chain_args(&s);
+    hipError_t e = hipMemsetAsync(lq, 0, (size_t)s.ld * sizeof(double), g_stream);
+    if (e == hipSuccess) e = hipMemsetAsync(outp, 0, (size_t)s.dp * s.ld * sizeof(double), g_stream);
+    if (e == hipSuccess) {
+        if (p->kind == kRW) {
+            rc = sync_proposal(p);
+            if (!rc) {
+                RwArgs ra{p->d_Ltiles, nullptr};
+                e = launch_propose_rw(p->NT, ra, c, outp, g_stream); // logqratio = 0.0, randomwalk.py:26
+            }
+        } else {
+            HmcArgs ha{p->eps, p->nsteps};
+            if (m->kind == kGauss) e = launch_gauss_propose_hmc(m->NT, m->ga, ha, c, outp, lq, g_stream);
+            else if (m->kind == kLogReg) e = launch_logreg_propose_hmc(m->NT, m->la, ha, c, outp, lq, g_stream);
+            else rc = fail(RMH_ERR_PARAM, "hmc: this model has no gradient");
+        }
+    }
+    if (!rc && e == hipSuccess) e = launch_transpose_dn_to_nd(outp, nd, N, s.d, s.ld, 1, g_stream);
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(theta_p, nd, (size_t)N * s.d * sizeof(double), hipMemcpyDeviceToHost, g_stream);
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(logq, lq, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, g_stream);
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(dev.data(), s.rng, dev.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, g_stream);
+    if (!rc && e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    (void)hipFree(outp); (void)hipFree(lq); (void)hipFree(nd);
+    if (rc) return rc;
+    RMH_HIP(e);
+    rng_from_device_layout(dev, N, s.ld, rng);
+    return RMH_OK;
+}
+
+// -------------------------------------------------------------------- state
+int rmh_state_create(rmh_model_t m, int64_t N, uint64_t seed, uint64_t chain0, rmh_state_t *out)
+{
+    RMH_NEED_INIT();
+    if (!m || N < 1) return fail(RMH_ERR_PARAM, "state: need a model and N >= 1 chains");
+    rmh_state *s = new rmh_state;
+    s->m = m;
+    s->N = N;
+    s->ld = pad16(N);
+    s->d = m->d;
+    s->NT = m->NT;
+    s->dp = 16 * m->NT;
+    s->ks = (m->d + 3) / 4;
+    int rc;
+    if ((rc = dev_alloc(&s->theta, (size_t)s->dp * s->ld)) || (rc = dev_alloc(&s->logpost, (size_t)s->ld)) ||
+        (rc = dev_alloc(&s->rng, (size_t)16 * s->ld))) {
+        rmh_state_free(s);
+        return rc;
+    }
+    hipError_t e = hipMemsetAsync(s->theta, 0, (size_t)s->dp * s->ld * sizeof(double), g_stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->logpost, 0, (size_t)s->ld * sizeof(double), g_stream);
+    if (e == hipSuccess) e = launch_rng_seed(s->rng, s->ld, seed, chain0, g_stream);
+    if (e != hipSuccess) {
+        rmh_state_free(s);
+        RMH_HIP(e);
+    }
+    *out = s;
+    return RMH_OK;
+}
+
+int rmh_state_set_theta(rmh_state_t s, const double *theta)
+{
+    RMH_NEED_INIT();
+    if (!s || !theta) return fail(RMH_ERR_PARAM, "bad argument");
+    double *staging = nullptr;
+    int rc = upload(&staging, theta, (size_t)s->N * s->d);
+    if (rc) return rc;
+    hipError_t e = hipMemsetAsync(s->theta, 0, (size_t)s->dp * s->ld * sizeof(double), g_stream);
+    if (e == hipSuccess) e = launch_transpose_nd_to_dn(staging, s->theta, s->N, s->d, s->ld, g_stream);
+    if (e == hipSuccess) {
+        ChainArgs c = chain_args(s);
+        rc = eval_states(s->m, c, false, s->logpost, nullptr, nullptr, nullptr); // sampler.py:42
+    }
+    hipError_t e2 = hipStreamSynchronize(g_stream);
+    (void)hipFree(staging);
+    if (rc) return rc;
+    RMH_HIP(e);
+    RMH_HIP(e2);
+    s->valid = true;
+    s->grad_valid = false;
+    return RMH_OK;
+}
+
+int rmh_state_get(rmh_state_t s, double *theta, double *logpost)
+{
+    RMH_NEED_INIT();
+    if (!s) return fail(RMH_ERR_PARAM, "null state");
+    if (!s->valid) return fail(RMH_ERR_STATE, "state: no current state (empty history)");
+    if (theta) {
+        double *nd = nullptr;
+        int rc = dev_alloc(&nd, (size_t)s->N * s->d);
+        if (rc) return rc;
+        hipError_t e = launch_transpose_dn_to_nd(s->theta, nd, s->N, s->d, s->ld, 1, g_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(theta, nd, (size_t)s->N * s->d * sizeof(double), hipMemcpyDeviceToHost, g_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        (void)hipFree(nd);
+        RMH_HIP(e);
+    }
+    if (logpost) {
+        RMH_HIP(hipMemcpyAsync(logpost, s->logpost, (size_t)s->N * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+        RMH_HIP(hipStreamSynchronize(g_stream));
+    }
+    return RMH_OK;
+}
+
+int rmh_state_get_rng(rmh_state_t s, uint64_t *rng)
+{
+    RMH_NEED_INIT();
+    if (!s || !rng) return fail(RMH_ERR_PARAM, "bad argument");
+    std::vector<uint64_t> dev((size_t)16 * s->ld);
+    RMH_HIP(hipMemcpyAsync(dev.data(), s->rng, dev.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, g_stream));
+    RMH_HIP(hipStreamSynchronize(g_stream));
+    rng_from_device_layout(dev, s->N, s->ld, rng);
+    return RMH_OK;
+}
+
+int rmh_state_set_rng(rmh_state_t s, const uint64_t *rng)
+{
+    RMH_NEED_INIT();
+    if (!s || !rng) return fail(RMH_ERR_PARAM, "bad argument");
+    std::vector<uint64_t> dev;
+    rng_to_device_layout(rng, s->N, s->ld, dev);
+    RMH_HIP(hipMemcpyAsync(s->rng, dev.data(), dev.size() * sizeof(uint64_t), hipMemcpyHostToDevice, g_stream));
+    RMH_HIP(hipStreamSynchronize(g_stream));
+    return RMH_OK;
+}
+
+int rmh_state_device_ptrs(rmh_state_t s, void **theta_dn, void **logpost, int64_t *ld)
+{
+    if (!s) return fail(RMH_ERR_PARAM, "null state");
+    if (theta_dn) *theta_dn = s->theta;
+    if (logpost) *logpost = s->logpost;
+    if (ld) *ld = s->ld;
+    return RMH_OK;
+}
+
+int rmh_state_free(rmh_state_t s)
+{
+    if (!s) return RMH_OK;
+    (void)hipFree(s->theta);
+    (void)hipFree(s->grad);
+    (void)hipFree(s->logpost);
+    (void)hipFree(s->rng);
+    delete s;
+    return RMH_OK;
+}
+
+// ------------------------------------------------------------------ history
+int rmh_history_create(rmh_state_t s, int64_t entries, int64_t iters, rmh_history_t *out)
+{
+    RMH_NEED_INIT();
+    if (!s || entries < 0 || iters < 0) return fail(RMH_ERR_PARAM, "bad argument");
+    rmh_history *h = new rmh_history;
+    h->s = s;
+    h->entries = entries;
+    h->iters = iters;
+    int rc;
+    if ((rc = dev_alloc(&h->thetas, (size_t)entries * 4 * s->ks * s->ld)) ||
+        (rc = dev_alloc(&h->logpost, (size_t)entries * s->ld)) ||
+        (rc = dev_alloc(&h->accept, (size_t)iters * s->ld))) {
+        rmh_history_free(h);
+        return rc;
+    }
+    if (entries > 0) // rows d..4*ks-1 of an entry are never written by the lane kernels
+        RMH_HIP(hipMemsetAsync(h->thetas, 0, (size_t)entries * 4 * s->ks * s->ld * sizeof(double), g_stream));
+    *out = h;
+    return RMH_OK;
+}
+
+int rmh_history_entries(rmh_history_t h, int64_t *entries, int64_t *iters)
+{
+    if (!h) return fail(RMH_ERR_PARAM, "null history");
+    if (entries) *entries = h->entries;
+    if (iters) *iters = h->iters;
+    return RMH_OK;
+}
+
+int rmh_history_download(rmh_history_t h, int64_t e0, int64_t e1, double *thetas, double *logpost)
+{
+    RMH_NEED_INIT();
+    if (!h || e0 < 0 || e1 > h->entries || e0 > e1) return fail(RMH_ERR_PARAM, "history: bad entry range");
+    const rmh_state *s = h->s;
+    const int64_t rows = 4 * s->ks, per = s->N * s->d;
+    if (thetas && e1 > e0) {
+        // transpose on the device in chunks of <= 256 MiB
+        int64_t chunk = (256LL << 20) / (per * 8);
+        if (chunk < 1) chunk = 1;
+        if (chunk > e1 - e0) chunk = e1 - e0;
+        double *nd = nullptr;
+        int rc = dev_alloc(&nd, (size_t)chunk * per);
+        if (rc) return rc;
+        hipError_t e = hipSuccess;
+        for (int64_t a = e0; a < e1 && e == hipSuccess; a += chunk) {
+            const int64_t n = (e1 - a < chunk) ? e1 - a : chunk;
+            // entries are 4*ks rows apart; the transpose kernel strides by d rows, so go one
+            // entry at a time when the two differ
+            if (rows == s->d) {
+                e = launch_transpose_dn_to_nd(h->thetas + a * rows * s->ld, nd, s->N, s->d, s->ld, n, g_stream);
+            } else {
+                for (int64_t k = 0; k < n && e == hipSuccess; ++k)
+                    e = launch_transpose_dn_to_nd(h->thetas + (a + k) * rows * s->ld, nd + k * per,
+                                                  s->N, s->d, s->ld, 1, g_stream);
+            }
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(thetas + (a - e0) * per, nd, (size_t)n * per * sizeof(double),
+                                   hipMemcpyDeviceToHost, g_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        }
+        (void)hipFree(nd);
+        RMH_HIP(e);
+    }
+    if (logpost && e1 > e0) {
+        RMH_HIP(hipMemcpy2DAsync(logpost, (size_t)s->N * sizeof(double), h->logpost + e0 * s->ld,
+                                 (size_t)s->ld * sizeof(double), (size_t)s->N * sizeof(double),
+                                 (size_t)(e1 - e0), hipMemcpyDeviceToHost, g_stream));
+        RMH_HIP(hipStreamSynchronize(g_stream));
+    }
+    return RMH_OK;
+}
+
+int rmh_history_accept(rmh_history_t h, int64_t t0, int64_t t1, uint8_t *accept)
+{
+    RMH_NEED_INIT();
+    if (!h || !accept || t0 < 0 || t1 > h->iters || t0 > t1) return fail(RMH_ERR_PARAM, "history: bad iteration range");
+    if (t1 == t0) return RMH_OK;
+    const rmh_state *s = h->s;
+    RMH_HIP(hipMemcpy2DAsync(accept, (size_t)s->N, h->accept + t0 * s->ld, (size_t)s->ld, (size_t)s->N,
+                             (size_t)(t1 - t0), hipMemcpyDeviceToHost, g_stream));
+    RMH_HIP(hipStreamSynchronize(g_stream));
+    return RMH_OK;
+}
+
+int rmh_history_device_ptrs(rmh_history_t h, void **thetas_edn, void **logpost_en, void **accept_tn, int64_t *ld)
+{
+    if (!h) return fail(RMH_ERR_PARAM, "null history");
+    if (thetas_edn) *thetas_edn = h->thetas;
+    if (logpost_en) *logpost_en = h->logpost;
+    if (accept_tn) *accept_tn = h->accept;
+    if (ld) *ld = h->s->ld;
+    return RMH_OK;
+}
+
+int rmh_history_free(rmh_history_t h)
+{
+    if (!h) return RMH_OK;
+    (void)hipFree(h->thetas);
+    (void)hipFree(h->logpost);
+    (void)hipFree(h->accept);
+    delete h;
+    return RMH_OK;
+}
+
+// ---------------------------------------------------------------------- run
+int rmh_run(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t nburn,
+            int64_t nthin, rmh_history_t h)
+{
+    RMH_NEED_INIT();
+    if (!m || !p || !s) return fail(RMH_ERR_PARAM, "run: null handle");
+    if (s->m != m) return fail(RMH_ERR_PARAM, "run: state belongs to another model");
+    if (p->d != m->d) return fail(RMH_ERR_PARAM, "theta and L have incompatible shapes"); // randomwalk.py:24
+    if (T < 0 || nburn < 0 || nthin < 1) return fail(RMH_ERR_PARAM, "run: need Nsamples >= 0, Nburn >= 0, Nthin >= 1");
+    if (!s->valid) return fail(RMH_ERR_STATE, "run: no current state (set theta0 first, or the previous run kept nothing)");
+    const int64_t kept = (T >= nburn) ? (T - nburn) / nthin + 1 : 0;
+    if (h) {
+        if (h->s != s) return fail(RMH_ERR_PARAM, "run: history belongs to another state");
+        if (h->entries < kept || h->iters < T) return fail(RMH_ERR_PARAM, "run: history too small");
+    }
+    int rc;
+    if (p->kind == kHMC) {
+        if (m->kind == kChangepoint)
+            return fail(RMH_ERR_PARAM, "hmc: the changepoint model has no gradient");
+        if ((rc = ensure_grad(s))) return rc;
+    } else if ((rc = sync_proposal(p))) {
+        return rc;
+    }
+    ChainArgs c = chain_args(s);
+    RunArgs r{};
+    r.T = T;
+    r.nburn = nburn;
+    r.nthin = nthin;
+    r.h_theta = h ? h->thetas : nullptr;
+    r.h_logpost = h ? h->logpost : nullptr;
+    r.h_accept = h ? h->accept : nullptr;
+    RMH_HIP(hipEventRecord(g_ev0, g_stream));
+    hipError_t e = hipSuccess;
+    if (p->kind == kRW) {
+        RwArgs ra{p->d_Ltiles, nullptr};
+        if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, g_stream);
+        else if (m->kind == kChangepoint) e = launch_cp_rw(m->k, m->ca, ra, c, r, g_stream);
+        else return fail(RMH_ERR_PARAM, "run: random walk on the logistic model is not built yet");
+    } else {
+        HmcArgs ha{p->eps, p->nsteps};
+        if (m->kind == kGauss) e = launch_gauss_hmc(m->NT, m->ga, ha, c, r, g_stream);
+        else e = launch_logreg_hmc(m->NT, m->la, ha, c, r, g_stream);
+    }
+    RMH_HIP(e);
+    RMH_HIP(hipEventRecord(g_ev1, g_stream));
+    g_timed = true;
+    g_last_launches = 1;
+    // the chain's current state is the LAST KEPT entry (sampler.py:49-50, 53-54)
+    if (kept == 0) {
+        s->valid = false;
+    } else if (h) {
+        const int64_t last = nburn + (kept - 1) * nthin;
+        if (last != T) {
+            const int64_t rows = 4 * s->ks;
+            RMH_HIP(hipMemcpyAsync(s->theta, h->thetas + (kept - 1) * rows * s->ld,
+                                   (size_t)rows * s->ld * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
+            RMH_HIP(hipMemcpyAsync(s->logpost, h->logpost + (kept - 1) * s->ld,
+                                   (size_t)s->ld * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
+            s->grad_valid = false;
+        }
+    }
+    return RMH_OK;
+}
+
+// --------------------------------------------------------------- test hooks
+int rmh_debug_rng_stream(uint64_t seed, uint64_t chain0, int64_t N, int d, int T, double *xi, double *u)
+{
+    RMH_NEED_INIT();
+    if (N < 1 || d < 1 || T < 1) return fail(RMH_ERR_PARAM, "bad argument");
+    const int64_t ld = pad16(N);
+    uint64_t *rng = nullptr;
+    double *dxi = nullptr, *du = nullptr;
+    int rc;
+    if ((rc = dev_alloc(&rng, (size_t)16 * ld)) || (rc = dev_alloc(&dxi, (size_t)T * ld * d)) ||
+        (rc = dev_alloc(&du, (size_t)T * ld))) {
+        (void)hipFree(rng); (void)hipFree(dxi); (void)hipFree(du);
+        return rc;
+    }
+    hipError_t e = launch_rng_seed(rng, ld, seed, chain0, g_stream);
+    if (e == hipSuccess) e = launch_rng_stream(rng, ld, d, T, dxi, du, g_stream);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(xi, (size_t)N * d * 8, dxi, (size_t)ld * d * 8, (size_t)N * d * 8, (size_t)T,
+                             hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(u, (size_t)N * 8, du, (size_t)ld * 8, (size_t)N * 8, (size_t)T,
+                             hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    (void)hipFree(rng); (void)hipFree(dxi); (void)hipFree(du);
+    RMH_HIP(e);
+    return RMH_OK;
+}
+
+int rmh_debug_mfma(const double *A, const double *B, const double *C, double *D)
+{
+    RMH_NEED_INIT();
+    double *dA = nullptr, *dB = nullptr, *dC = nullptr, *dD = nullptr;
+    int rc;
+    if ((rc = upload(&dA, A, 64)) || (rc = upload(&dB, B, 64)) || (rc = upload(&dC, C, 256)) ||
+        (rc = dev_alloc(&dD, 256))) {
+        (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dD);
+        return rc;
+    }
+    hipError_t e = launch_debug_mfma(dA, dB, dC, dD, g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(D, dD, 256 * sizeof(double), hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dD);
+    RMH_HIP(e);
+    return RMH_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,207 @@
+// rmh_device.hpp -- device-side random stream and elementary functions (gfx950).
+//
+// "rmh-rng v1" (Random stream): chain c owns four xoshiro256++
+// sub-streams g = 0..3 (stream id 4c+g).  In the MFMA kernels the four lanes
+// {cl, cl+16, cl+32, cl+48} of a wavefront hold one chain and lane group g owns
+// sub-stream g and the coordinates j = g (mod 4) -- exactly the B-operand
+// layout of v_mfma_f64_16x16x4_f64, so normals are born in the register they
+// are consumed from.  log / sincos are defined operation by operation (explicit
+// fma; the file is compiled with -ffp-contract=off) so that the stream is
+// bit-identical to the CPU oracle's restatement of the same spec.
+//
+// Replaces the process-global numpy generator used by the reference at
+// riemann/proposals/randomwalk.py:25, riemann/proposals/hamiltonian.py:79 and
+// riemann/samplers/sampler.py:84.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rmh {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+#define RMH_DEV __device__ __forceinline__
+
+constexpr uint64_t kGamma = 0x9E3779B97F4A7C15ULL;
+
+RMH_DEV uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+struct Xo {
+    uint64_t s0, s1, s2, s3;
+};
+
+RMH_DEV uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+RMH_DEV void xo_init(Xo &x, uint64_t seed, uint64_t sid)
+{
+    uint64_t v = mix64(mix64(seed + kGamma) + sid);
+    v += kGamma; x.s0 = mix64(v);
+    v += kGamma; x.s1 = mix64(v);
+    v += kGamma; x.s2 = mix64(v);
+    v += kGamma; x.s3 = mix64(v);
+}
+
+RMH_DEV uint64_t xo_next(Xo &x)
+{
+    const uint64_t r = rotl64(x.s0 + x.s3, 23) + x.s0;
+    const uint64_t t = x.s1 << 17;
+    x.s2 ^= x.s0;
+    x.s3 ^= x.s1;
+    x.s1 ^= x.s2;
+    x.s0 ^= x.s3;
+    x.s2 ^= t;
+    x.s3 = rotl64(x.s3, 45);
+    return r;
+}
+
+// rng state in global memory: word w of stream (chain c, group g) lives at
+// rng[w * 4*Npad + (c/16)*64 + g*16 + c%16]  (one coalesced 512-B row per wave)
+RMH_DEV int64_t rng_slot(int64_t c, int g) { return (c >> 4) * 64 + g * 16 + (c & 15); }
+
+RMH_DEV Xo xo_load(const uint64_t *rng, int64_t nslots, int64_t slot)
+{
+    Xo x;
+    x.s0 = rng[slot];
+    x.s1 = rng[nslots + slot];
+    x.s2 = rng[2 * nslots + slot];
+    x.s3 = rng[3 * nslots + slot];
+    return x;
+}
+
+RMH_DEV void xo_store(uint64_t *rng, int64_t nslots, int64_t slot, const Xo &x)
+{
+    rng[slot] = x.s0;
+    rng[nslots + slot] = x.s1;
+    rng[2 * nslots + slot] = x.s2;
+    rng[3 * nslots + slot] = x.s3;
+}
+
+RMH_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// log core: x positive, normal, finite; the result is log(x) + koff*ln2 with the
+// exponent offset applied BEFORE the final expression (as the oracle does for
+// subnormal inputs: k = -54 after scaling by 2^54).
+RMH_DEV double log_core(double x, int koff)
+{
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                     Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                     Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                     Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                     Lg7 = 1.479819860511658591e-01;
+    const uint64_t ix = (uint64_t)__double_as_longlong(x);
+    int k = (int)(ix >> 52) - 1023 + koff;
+    const uint64_t mant = ix & 0x000FFFFFFFFFFFFFULL;
+    const bool hi = mant >= 0x0006A09E667F3BCDULL;
+    const double m = __longlong_as_double(
+        (long long)(mant | (hi ? 0x3FE0000000000000ULL : 0x3FF0000000000000ULL)));
+    k += hi ? 1 : 0;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma_(w, fma_(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma_(w, fma_(w, fma_(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * ln2_hi - ((hfsq - fma_(s, hfsq + R, dk * ln2_lo)) - f);
+}
+
+// log of a positive, normal, finite double (all the stream needs): no specials.
+RMH_DEV double log_pos(double x) { return log_core(x, 0); }
+
+// log with IEEE/numpy specials: nan->nan, <0 -> nan, 0 -> -inf, inf -> inf,
+// subnormals rescaled by 2^54.
+RMH_DEV double log_full(double x)
+{
+    const double inf = __builtin_huge_val();
+    const bool ok = (x > 0.0) && (x < inf);
+    const bool sub = x < 2.2250738585072014e-308;
+    const double xs = sub ? x * 0x1p54 : x;
+    double r = log_core(ok ? xs : 1.0, sub ? -54 : 0);
+    if (!ok) {
+        if (x != x) r = x;
+        else if (x < 0.0) r = __builtin_nan("");
+        else if (x == 0.0) r = -inf;
+        else r = x; // +inf
+    }
+    return r;
+}
+
+// sin(2 pi u), cos(2 pi u), u in [0,1)
+RMH_DEV void sincos2pi(double u, double &sn, double &cs)
+{
+    constexpr double TWO_PI = 6.283185307179586476925,
+                     S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                     S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                     S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10,
+                     C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                     C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                     C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double q = __builtin_floor(fma_(4.0, u, 0.5));
+    const double r = fma_(-0.25, q, u);
+    const double x = r * TWO_PI;
+    const double z = x * x;
+    const double ps = fma_(z, fma_(z, fma_(z, fma_(z, S6, S5), S4), S3), S2);
+    const double sx = fma_(x * z, fma_(z, ps, S1), x);
+    const double pc = fma_(z, fma_(z, fma_(z, fma_(z, fma_(z, C6, C5), C4), C3), C2), C1);
+    const double zz = z * z;
+    const double cx = 1.0 - fma_(-zz, pc, 0.5 * z);
+    const int qi = ((int)q) & 3;
+    const bool swap = qi & 1;
+    const double a = swap ? cx : sx;  // |sin|
+    const double b = swap ? sx : cx;  // |cos|
+    sn = (qi & 2) ? -a : a;
+    cs = ((qi + 1) & 2) ? -b : b;
+}
+
+constexpr double k2m53 = 0x1p-53;
+
+// one Box-Muller pair from one sub-stream
+RMH_DEV void normal_pair(Xo &x, double &z0, double &z1)
+{
+    const uint64_t a = xo_next(x), b = xo_next(x);
+    const double u1 = (double)((a >> 11) + 1) * k2m53; // (0,1]
+    const double u2 = (double)(b >> 11) * k2m53;       // [0,1)
+    const double r = __builtin_sqrt(-2.0 * log_pos(u1));
+    double sn, cs;
+    sincos2pi(u2, sn, cs);
+    z0 = r * cs;
+    z1 = r * sn;
+}
+
+RMH_DEV double u01(uint64_t r) { return (double)(r >> 11) * k2m53; }
+
+// sum over the four lanes {cl, cl+16, cl+32, cl+48} that hold one chain
+RMH_DEV double sum4(double x)
+{
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+}
+
+// Model.log_posterior, riemann/models/model.py:49-55
+RMH_DEV double combine_post(double logP, double logL)
+{
+    const double inf = __builtin_huge_val();
+    const bool bad = (logP != logP) || (logL != logL) || logP == inf || logP == -inf ||
+                     logL == inf || logL == -inf;
+    return bad ? -inf : logP + logL;
+}
+
+// Sampler.sample, riemann/samplers/sampler.py:83-84, with PYTHON min(0, D):
+// D if D < 0 else 0, so a NaN ratio accepts.
+RMH_DEV bool mh_accept(double lp_prop, double lp_old, double logq, double u)
+{
+    const double delta = lp_prop - lp_old - logq;
+    const double mh = (delta < 0.0) ? delta : 0.0;
+    const double lu = (u > 0.0) ? log_pos(u) : -__builtin_huge_val();
+    return lu < mh;
+}
+
+} // namespace rmh

@@ -1,0 +1,116 @@
+// rmh_internal.hpp -- structures shared by the kernel files and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+namespace rmh {
+
+enum ModelKind { kGauss = 1, kLogReg = 2, kChangepoint = 3 };
+enum ProposalKind { kRW = 1, kHMC = 2 };
+
+// ---- device-side argument blocks (passed by value to the kernels) ----------
+struct GaussArgs {
+    const double *Wtiles;  // lower-triangular tile image of W = L^-1
+    const double *WTtiles; // upper-triangular tile image of W^T (gradient)
+    const double *mu_pad;  // 16*NT doubles, zero padded
+    double dlog2pi;        // d*log(2 pi)
+    double logdetC;
+};
+
+struct LogRegArgs {
+    const double *Ximg;    // per 16-row tile: 4*NT swizzled 16x4 tiles (512 B each)
+    const double *yw;      // per 16-row tile: y[16], w[16]
+    int64_t nrt;           // row tiles
+    double inv_tau2;
+    double two_tau2;
+};
+
+struct CpArgs {
+    const double *xy;      // x[n], y[n]
+    int n;
+    double xmin, xmax, alpha_m1, beta;
+    double c_k;            // k' log(lamb) - lgamma(k') - lamb          (k' = pieces)
+    double c_v;            // per piece: alpha log(beta)                 (added per element)
+    double lgam_alpha;     // lgamma(alpha)                              (subtracted per element)
+    double c_s;            // lgamma(2k'+1)
+    double c_sL;           // k' log(xmax-xmin)
+    double nlog2pi;        // n log(2 pi)
+};
+
+struct ChainArgs {
+    double *theta;      // (dp, ld), rows >= d are zero
+    double *logpost;    // (ld)
+    double *grad;       // (dp, ld) cached gradient of the log posterior (HMC), or null
+    uint64_t *rng;      // 4 words x nslots
+    int64_t ld;         // padded chain count (multiple of 16)
+    int64_t nslots;     // 4*ld
+    int64_t nblocks;    // ld/16
+    int d;
+    int dp;             // rows of theta/grad: 16*NT (MFMA kernels)
+    int ks;             // ceil(d/4): history entries hold 4*ks rows
+    int P;              // Box-Muller pairs per sub-stream per iteration
+};
+
+struct RunArgs {
+    int64_t T, nburn, nthin;
+    double *h_theta;    // (entries, 4*ks, ld) or null
+    double *h_logpost;  // (entries, ld)
+    uint8_t *h_accept;  // (T, ld) or null
+};
+
+struct RwArgs {
+    const double *Ltiles; // lower-triangular tile image of scale*L (MFMA kernels)
+    const double *Ldense; // (d,d) row-major scale*L (lane kernels)
+};
+
+struct HmcArgs {
+    double eps;
+    int nsteps;
+};
+
+// tile counts of the triangular images
+constexpr int tri_tiles(int NT) { return 2 * NT * (NT + 1); }
+inline int nt_for_dim(int d) { return d <= 16 ? 1 : d <= 32 ? 2 : d <= 64 ? 4 : d <= 112 ? 7 : -1; }
+
+// ---- host-side launchers implemented in the kernel files --------------------
+// all return hipError_t of the launch
+hipError_t launch_gauss_eval(int NT, const GaussArgs &m, const ChainArgs &c, int want_grad,
+                             double *lp_out, double *grad_out, double *lprior_out,
+                             double *llik_out, hipStream_t st);
+hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
+                           const RunArgs &r, hipStream_t st);
+hipError_t launch_gauss_hmc(int NT, const GaussArgs &m, const HmcArgs &p, const ChainArgs &c,
+                            const RunArgs &r, hipStream_t st);
+hipError_t launch_propose_rw(int NT, const RwArgs &p, const ChainArgs &c, double *theta_p,
+                             hipStream_t st);
+hipError_t launch_gauss_propose_hmc(int NT, const GaussArgs &m, const HmcArgs &p,
+                                    const ChainArgs &c, double *theta_p, double *logq,
+                                    hipStream_t st);
+
+hipError_t launch_logreg_eval(int NT, const LogRegArgs &m, const ChainArgs &c, int want_grad,
+                              double *lp_out, double *grad_out, double *lprior_out,
+                              double *llik_out, hipStream_t st);
+hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, const ChainArgs &c,
+                             const RunArgs &r, hipStream_t st);
+hipError_t launch_logreg_propose_hmc(int NT, const LogRegArgs &m, const HmcArgs &p,
+                                     const ChainArgs &c, double *theta_p, double *logq,
+                                     hipStream_t st);
+
+hipError_t launch_cp_eval(int k, const CpArgs &m, const ChainArgs &c, double *lprior,
+                          double *llik, double *lpost, hipStream_t st);
+hipError_t launch_cp_rw(int k, const CpArgs &m, const RwArgs &p, const ChainArgs &c,
+                        const RunArgs &r, hipStream_t st);
+
+hipError_t launch_rng_seed(uint64_t *rng, int64_t ld, uint64_t seed, uint64_t chain0,
+                           hipStream_t st);
+hipError_t launch_rng_stream(uint64_t *rng, int64_t ld, int d, int T, double *xi, double *u,
+                             hipStream_t st);
+hipError_t launch_transpose_nd_to_dn(const double *src, double *dst, int64_t N, int d,
+                                     int64_t ld, hipStream_t st);
+hipError_t launch_transpose_dn_to_nd(const double *src, double *dst, int64_t N, int d,
+                                     int64_t ld, int64_t entries, hipStream_t st);
+hipError_t launch_debug_mfma(const double *A, const double *B, const double *C, double *D,
+                             hipStream_t st);
+
+} // namespace rmh

@@ -1,0 +1,294 @@
+// rmh_kernels_cp.hip -- changepoint regression at fixed k (BASELINE.json cfg 5):
+//   ChangepointRegression1D.log_prior / log_likelihood / predict,
+//   riemann/models/changepoint.py:106-160, 175-181, log_gamma_dist :18-19,
+// sampled by a full-vector MetropolisRandomWalk (proposals/randomwalk.py:21-26)
+// whose covariance is the block diagonal of riemann/test_changepoint.py:36-38.
+//
+// Layout: the same four-lanes-per-chain wavefront tile as the MFMA kernels
+// (lane = 16*g + cl: chain cl of the wave's 16, sub-stream g), because the
+// random stream is defined that way.  theta (d = 2k+2 <= 18 doubles) is
+// replicated in the four lanes; the lanes split the work that dominates:
+//   normals    lane g draws coordinates j = g (mod 4), then a 4-lane exchange
+//   prior      lane g takes the logs of elements j = g (mod 4)
+//   likelihood lane g takes the data points i = g (mod 4); x, y sit in LDS
+// and partial sums meet in a 2-step xor butterfly.  HBM-bound on paper (104 B
+// per recorded sample), instruction-issue bound in practice.
+#include "rmh_internal.hpp"
+#include "rmh_mfma.hpp"
+
+namespace rmh {
+
+// an opaque copy: keeps a value in a VGPR as far as the optimiser can tell
+RMH_DEV double reg(double x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+template <int N>
+RMH_DEV double pick(const double (&a)[N], int base, int g)
+{
+    // a[base + g] for g in 0..3 with static register indices; 0 beyond N
+    const double v0 = (base + 0 < N) ? a[base + 0 < N ? base + 0 : 0] : 0.0;
+    const double v1 = (base + 1 < N) ? a[base + 1 < N ? base + 1 : 0] : 0.0;
+    const double v2 = (base + 2 < N) ? a[base + 2 < N ? base + 2 : 0] : 0.0;
+    const double v3 = (base + 3 < N) ? a[base + 3 < N ? base + 3 : 0] : 0.0;
+    return g == 0 ? v0 : g == 1 ? v1 : g == 2 ? v2 : v3;
+}
+
+template <int KC>
+struct CpModel {
+    static constexpr int D = 2 * KC + 2; // cpx[KC], cpv[KC+1], sig
+    static constexpr int KP = KC + 1;    // pieces ("k" of changepoint.py:133)
+
+    // log_prior, changepoint.py:128-160.  Returns NaN-mapped (-inf) value.
+    static RMH_DEV double log_prior(const CpArgs &m, const double (&th)[D], int g)
+    {
+        double cpv[KP], ds[KP];
+#pragma unroll
+        for (int j = 0; j < KP; ++j) cpv[j] = th[KC + j];
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const double lo = (j == 0) ? m.xmin : th[j - 1 < 0 ? 0 : j - 1];
+            const double hi = (j == KC) ? m.xmax : th[j < KC ? j : 0];
+            ds[j] = hi - lo; // s[1:] - s[:-1], :142-143
+        }
+        double pv = 0.0, ps = 0.0;
+#pragma unroll
+        for (int b = 0; b < KP; b += 4) {
+            const bool valid = b + g < KP;
+            const double v = valid ? pick<KP>(cpv, b, g) : 1.0;
+            const double dx = valid ? pick<KP>(ds, b, g) : 1.0;
+            // log_gamma_dist (:18-19): alpha log(beta) + (alpha-1) log(x) - beta x - lgamma(alpha)
+            const double tv = ((m.c_v + m.alpha_m1 * log_full(v)) - m.beta * v) - m.lgam_alpha;
+            const double ts = log_full(dx);
+            pv += valid ? tv : 0.0;
+            ps += valid ? ts : 0.0;
+        }
+        pv = sum4(pv);
+        ps = sum4(ps);
+        const double sig = th[D - 1];
+        double p2 = log_full(1.0 / (sig * sig)); // :145
+        if (sig < 0.0) p2 = __builtin_nan("");   // :146-147
+        double logP = ((m.c_k + pv) + ((m.c_s + ps) - m.c_sL)) + p2; // :156
+        if (logP != logP) logP = -__builtin_huge_val();             // :158-159
+        return logP;
+    }
+
+    // predict (:181) for one datum, valid when cpx is sorted (prior finite)
+    static RMH_DEV double predict_sorted(const double (&th)[D], double x)
+    {
+        // reg(): seen as plain array reads, LLVM rewrites the select chain into a
+        // select of ADDRESSES plus one scratch load per datum
+        double v = reg(th[KC]);
+#pragma unroll
+        for (int j = 0; j < KC; ++j) v = (th[j] < x) ? reg(th[KC + 1 + j]) : v;
+        return v;
+    }
+
+    // numpy searchsorted(cpx, x) side='left' as a bisection with static
+    // register indices (any cpx, sorted or not); returns cpv[index]
+    static RMH_DEV double predict_any(const double (&th)[D], double x, int &idx)
+    {
+        int lo = 0, hi = KC;
+#pragma unroll
+        for (int it = 0; it < 5; ++it) { // 2^5 > KC+1 for KC <= 16
+            if (lo < hi) {
+                const int mid = lo + ((hi - lo) >> 1);
+                double a = reg(th[0]);
+#pragma unroll
+                for (int j = 1; j < KC; ++j) a = (mid == j) ? reg(th[j]) : a;
+                if (a < x) lo = mid + 1; else hi = mid;
+            }
+        }
+        idx = lo;
+        double v = reg(th[KC]);
+#pragma unroll
+        for (int j = 1; j < KP; ++j) v = (lo == j) ? reg(th[KC + j]) : v;
+        return v;
+    }
+
+    // log_likelihood, changepoint.py:106-126
+    template <bool SORTED>
+    static RMH_DEV double log_lik(const double *xy, const CpArgs &m, const double (&th)[D], int g)
+    {
+        const double sig = th[D - 1], sig2 = sig * sig;
+        double ss = 0.0;
+        for (int i = g; i < m.n; i += 4) {
+            const double x = xy[i], y = xy[m.n + i];
+            int idx;
+            const double v = SORTED ? predict_sorted(th, x) : predict_any(th, x, idx);
+            const double r = v - y;
+            ss += r * r;
+        }
+        ss = sum4(ss) / sig2;
+        double logL = -0.5 * ((ss + m.n * log_full(sig2)) + m.nlog2pi); // :118-121
+        if (logL != logL) logL = -__builtin_huge_val();                 // :124-125
+        return logL;
+    }
+};
+
+template <int KC, int D>
+RMH_DEV void cp_load(const double *theta, int64_t ld, int64_t c, double (&th)[D])
+{
+#pragma unroll
+    for (int p = 0; p < D; ++p) th[p] = theta[(int64_t)p * ld + c];
+}
+
+// fused Sampler.run (samplers/sampler.py:44-90)
+template <int KC>
+__global__ void __launch_bounds__(256, 2) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
+{
+    using M = CpModel<KC>;
+    constexpr int D = M::D;
+    constexpr int NT = (D + 15) / 16, S = 4 * NT;
+    using T = Tile<NT>;
+    extern __shared__ double lds[];
+    double *xy = lds;                 // x[n], y[n]
+    double *Limg = lds + 2 * m.n;     // tile image of scale*L
+    for (int i = threadIdx.x; i < 2 * m.n; i += blockDim.x) xy[i] = m.xy[i];
+    for (int i = threadIdx.x; i < tri_tiles(NT) * 64; i += blockDim.x) Limg[i] = pr.Ltiles[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, g = lane >> 4;
+    const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (blk >= ch.nblocks) return;
+    const int64_t c = blk * 16 + cl, slot = blk * 64 + lane;
+
+    double th[D];
+    cp_load<KC, D>(ch.theta, ch.ld, c, th);
+    double lp = ch.logpost[c];
+    Xo rng = xo_load(ch.rng, ch.nslots, slot);
+
+    auto rec = [&](int64_t e) {
+        if (!run.h_theta) return;
+        const int64_t k = kept_entry(e, run.nburn, run.nthin);
+        if (k < 0) return;
+        double *dst = run.h_theta + k * (int64_t)(4 * ch.ks) * ch.ld;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (4 * s + g < D) dst[(int64_t)(4 * s + g) * ch.ld + c] = pick<D>(th, 4 * s, g);
+        if (g == 0) run.h_logpost[k * ch.ld + c] = lp;
+    };
+    rec(0);
+
+    for (int64_t t = 0; t < run.T; ++t) {
+        // theta' = theta + scale L xi  (randomwalk.py:26) on the matrix core, in the
+        // 4-lanes-per-chain tile; then the chain's lanes exchange their quarters
+        double xi[S];
+        T::normals(rng, ch.P, D, g, xi);
+        double4_t acc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            acc[i].x = pick<D>(th, 16 * i + 0, g);
+            acc[i].y = pick<D>(th, 16 * i + 4, g);
+            acc[i].z = pick<D>(th, 16 * i + 8, g);
+            acc[i].w = pick<D>(th, 16 * i + 12, g);
+        }
+        T::mul_lower(Limg + lane, xi, acc);
+        double loc[S], thp[D];
+        T::unpack(acc, loc);
+#pragma unroll
+        for (int j = 0; j < D; ++j) thp[j] = __shfl(loc[j >> 2], cl + 16 * (j & 3));
+
+        const double logP = M::log_prior(m, thp, g);
+        double lpp = -__builtin_huge_val();
+        // wave-level skip: only evaluate the likelihood where some chain needs it
+        if (__any(logP > -__builtin_huge_val())) {
+            const double logL = M::template log_lik<true>(xy, m, thp, g);
+            lpp = combine_post(logP, logL); // model.py:49-55
+        }
+        const double u = T::accept_uniform(rng, g, cl);
+        const bool ok = mh_accept(lpp, lp, 0.0, u);
+        if (ok) {
+#pragma unroll
+            for (int p = 0; p < D; ++p) th[p] = thp[p];
+            lp = lpp;
+        }
+        if (run.h_accept && g == 0) run.h_accept[t * ch.ld + c] = ok ? 1 : 0;
+        rec(t + 1);
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int p = 0; p < D; ++p) ch.theta[(int64_t)p * ch.ld + c] = th[p];
+        ch.logpost[c] = lp;
+    }
+    xo_store(ch.rng, ch.nslots, slot, rng);
+}
+
+// Model.log_prior / log_likelihood / log_posterior for the states in ch.theta
+template <int KC>
+__global__ void __launch_bounds__(256) k_cp_eval(CpArgs m, ChainArgs ch, double *lprior,
+                                                  double *llik, double *lpost)
+{
+    using M = CpModel<KC>;
+    constexpr int D = M::D;
+    extern __shared__ double lds[];
+    for (int i = threadIdx.x; i < 2 * m.n; i += blockDim.x) lds[i] = m.xy[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, g = lane >> 4;
+    const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (blk >= ch.nblocks) return;
+    const int64_t c = blk * 16 + cl;
+    double th[D];
+    cp_load<KC, D>(ch.theta, ch.ld, c, th);
+    const double logP = M::log_prior(m, th, g);
+    const double logL = M::template log_lik<false>(lds, m, th, g);
+    if (g == 0) {
+        if (lprior) lprior[c] = logP;
+        if (llik) llik[c] = logL;
+        if (lpost) lpost[c] = combine_post(logP, logL);
+    }
+}
+
+template <int KC>
+static hipError_t cp_rw_launch(const CpArgs &m, const RwArgs &p, const ChainArgs &c,
+                               const RunArgs &r, hipStream_t st)
+{
+    constexpr int D = 2 * KC + 2, NT = (D + 15) / 16;
+    const size_t lds = sizeof(double) * (2 * (size_t)m.n + tri_tiles(NT) * 64);
+    const int nw = 4;
+    const dim3 grid((unsigned)((c.nblocks + nw - 1) / nw));
+    hipLaunchKernelGGL(k_cp_rw<KC>, grid, dim3(64 * nw), lds, st, m, p, c, r);
+    return hipGetLastError();
+}
+
+template <int KC>
+static hipError_t cp_eval_launch(const CpArgs &m, const ChainArgs &c, double *a, double *b,
+                                 double *d, hipStream_t st)
+{
+    const size_t lds = sizeof(double) * 2 * (size_t)m.n;
+    const int nw = 4;
+    const dim3 grid((unsigned)((c.nblocks + nw - 1) / nw));
+    hipLaunchKernelGGL(k_cp_eval<KC>, grid, dim3(64 * nw), lds, st, m, c, a, b, d);
+    return hipGetLastError();
+}
+
+#define RMH_CP_DISPATCH(fn, ...)                       \
+    switch (k) {                                       \
+    case 1: return fn<1>(__VA_ARGS__);                 \
+    case 2: return fn<2>(__VA_ARGS__);                 \
+    case 3: return fn<3>(__VA_ARGS__);                 \
+    case 4: return fn<4>(__VA_ARGS__);                 \
+    case 5: return fn<5>(__VA_ARGS__);                 \
+    case 6: return fn<6>(__VA_ARGS__);                 \
+    case 7: return fn<7>(__VA_ARGS__);                 \
+    case 8: return fn<8>(__VA_ARGS__);                 \
+    default: return hipErrorInvalidValue;              \
+    }
+
+hipError_t launch_cp_rw(int k, const CpArgs &m, const RwArgs &p, const ChainArgs &c,
+                        const RunArgs &r, hipStream_t st)
+{
+    RMH_CP_DISPATCH(cp_rw_launch, m, p, c, r, st)
+}
+
+hipError_t launch_cp_eval(int k, const CpArgs &m, const ChainArgs &c, double *lprior,
+                          double *llik, double *lpost, hipStream_t st)
+{
+    RMH_CP_DISPATCH(cp_eval_launch, m, c, lprior, llik, lpost, st)
+}
+
+} // namespace rmh

@@ -1,0 +1,266 @@
+// rmh_kernels_mfma.hip -- instantiations and launchers of the MFMA kernels
+// (Gaussian and logistic-regression models; random-walk and HMC/MALA proposals)
+// plus the small utility kernels (stream seeding, layout transposes, test hooks).
+#include "rmh_run.hpp"
+
+namespace rmh {
+
+template <class K, class... A>
+static hipError_t launch(K kernel, int64_t nblocks, int nw, size_t lds_bytes, hipStream_t st,
+                         A... args)
+{
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    if (lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const dim3 grid((unsigned)((nblocks + nw - 1) / nw)), block(64 * nw);
+    hipLaunchKernelGGL(kernel, grid, block, lds_bytes, st, args...);
+    return hipGetLastError();
+}
+
+#define RMH_NT_DISPATCH(NT, ...)                     \
+    switch (NT) {                                    \
+    case 1: { constexpr int kNT = 1; __VA_ARGS__; }  \
+    case 2: { constexpr int kNT = 2; __VA_ARGS__; }  \
+    case 4: { constexpr int kNT = 4; __VA_ARGS__; }  \
+    case 7: { constexpr int kNT = 7; __VA_ARGS__; }  \
+    default: return hipErrorInvalidValue;            \
+    }
+
+// ------------------------------------------------------------------ Gaussian
+hipError_t launch_gauss_eval(int NT, const GaussArgs &m, const ChainArgs &c, int want_grad,
+                             double *lp_out, double *grad_out, double *lprior_out,
+                             double *llik_out, hipStream_t st)
+{
+    RMH_NT_DISPATCH(NT, {
+        using M = GaussModel<kNT>;
+        const size_t lds = sizeof(double) * M::lds_doubles(want_grad);
+        if (want_grad)
+            return launch(k_eval<M, true, 4>, c.nblocks, 4, lds, st, m, c, lp_out, grad_out,
+                          lprior_out, llik_out);
+        return launch(k_eval<M, false, 4>, c.nblocks, 4, lds, st, m, c, lp_out, grad_out,
+                      lprior_out, llik_out);
+    })
+}
+
+hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
+                           const RunArgs &r, hipStream_t st)
+{
+    RMH_NT_DISPATCH(NT, {
+        using M = GaussModel<kNT>;
+        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false));
+        constexpr int NW = 4;
+        return launch(k_run_rw<M, NW>, c.nblocks, NW, lds, st, m, p, c, r);
+    })
+}
+
+hipError_t launch_gauss_hmc(int NT, const GaussArgs &m, const HmcArgs &p, const ChainArgs &c,
+                            const RunArgs &r, hipStream_t st)
+{
+    RMH_NT_DISPATCH(NT, {
+        using M = GaussModel<kNT>;
+        const size_t lds = sizeof(double) * M::lds_doubles(true);
+        return launch(k_run_hmc<M, 4>, c.nblocks, 4, lds, st, m, p, c, r);
+    })
+}
+
+hipError_t launch_propose_rw(int NT, const RwArgs &p, const ChainArgs &c, double *theta_p,
+                             hipStream_t st)
+{
+    RMH_NT_DISPATCH(NT, {
+        const size_t lds = sizeof(double) * tri_tiles(kNT) * 64;
+        return launch(k_propose_rw<kNT, 4>, c.nblocks, 4, lds, st, p, c, theta_p);
+    })
+}
+
+hipError_t launch_gauss_propose_hmc(int NT, const GaussArgs &m, const HmcArgs &p,
+                                    const ChainArgs &c, double *theta_p, double *logq,
+                                    hipStream_t st)
+{
+    RMH_NT_DISPATCH(NT, {
+        using M = GaussModel<kNT>;
+        const size_t lds = sizeof(double) * M::lds_doubles(true);
+        return launch(k_propose_hmc<M, 4>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
+    })
+}
+
+// ------------------------------------------------------- logistic regression
+hipError_t launch_logreg_eval(int NT, const LogRegArgs &m, const ChainArgs &c, int want_grad,
+                              double *lp_out, double *grad_out, double *lprior_out,
+                              double *llik_out, hipStream_t st)
+{
+    RMH_NT_DISPATCH(NT, {
+        using M = LogRegModel<kNT>;
+        const size_t lds = sizeof(double) * M::lds_doubles(true);
+        if (want_grad)
+            return launch(k_eval<M, true, 4>, c.nblocks, 4, lds, st, m, c, lp_out, grad_out,
+                          lprior_out, llik_out);
+        return launch(k_eval<M, false, 4>, c.nblocks, 4, lds, st, m, c, lp_out, grad_out,
+                      lprior_out, llik_out);
+    })
+}
+
+hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, const ChainArgs &c,
+                             const RunArgs &r, hipStream_t st)
+{
+    RMH_NT_DISPATCH(NT, {
+        using M = LogRegModel<kNT>;
+        const size_t lds = sizeof(double) * M::lds_doubles(true);
+        return launch(k_run_hmc<M, 4>, c.nblocks, 4, lds, st, m, p, c, r);
+    })
+}
+
+hipError_t launch_logreg_propose_hmc(int NT, const LogRegArgs &m, const HmcArgs &p,
+                                     const ChainArgs &c, double *theta_p, double *logq,
+                                     hipStream_t st)
+{
+    RMH_NT_DISPATCH(NT, {
+        using M = LogRegModel<kNT>;
+        const size_t lds = sizeof(double) * M::lds_doubles(true);
+        return launch(k_propose_hmc<M, 4>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
+    })
+}
+
+// ------------------------------------------------------------------ utilities
+__global__ void k_rng_seed(uint64_t *rng, int64_t nslots, uint64_t seed, uint64_t chain0)
+{
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nslots) return;
+    const int64_t c = (slot >> 6) * 16 + (slot & 15);
+    const int g = (int)((slot >> 4) & 3);
+    Xo x;
+    xo_init(x, seed, 4 * (chain0 + (uint64_t)c) + (uint64_t)g);
+    xo_store(rng, nslots, slot, x);
+}
+
+hipError_t launch_rng_seed(uint64_t *rng, int64_t ld, uint64_t seed, uint64_t chain0,
+                           hipStream_t st)
+{
+    const int64_t nslots = 4 * ld;
+    hipLaunchKernelGGL(k_rng_seed, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, rng,
+                       nslots, seed, chain0);
+    return hipGetLastError();
+}
+
+// xi (T, ld, d) and u (T, ld) exactly as the fused kernels draw them
+__global__ void k_rng_stream(uint64_t *rng, int64_t ld, int d, int T, double *xi, double *u)
+{
+    const int lane = threadIdx.x & 63, cl = lane & 15, g = lane >> 4;
+    const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (blk >= ld / 16) return;
+    const int64_t c = blk * 16 + cl, slot = blk * 64 + lane, nslots = 4 * ld;
+    Xo x = xo_load(rng, nslots, slot);
+    const int P = ((d + 3) / 4 + 1) / 2;
+    for (int t = 0; t < T; ++t) {
+        for (int p = 0; p < P; ++p) {
+            double z0, z1;
+            normal_pair(x, z0, z1);
+            const int j0 = 4 * (2 * p) + g, j1 = 4 * (2 * p + 1) + g;
+            if (j0 < d) xi[((int64_t)t * ld + c) * d + j0] = z0;
+            if (j1 < d) xi[((int64_t)t * ld + c) * d + j1] = z1;
+        }
+        const double uu = Tile<1>::accept_uniform(x, g, cl);
+        if (g == 0) u[(int64_t)t * ld + c] = uu;
+    }
+    xo_store(rng, nslots, slot, x);
+}
+
+hipError_t launch_rng_stream(uint64_t *rng, int64_t ld, int d, int T, double *xi, double *u,
+                             hipStream_t st)
+{
+    const int64_t nblocks = ld / 16;
+    hipLaunchKernelGGL(k_rng_stream, dim3((unsigned)((nblocks + 3) / 4)), dim3(256), 0, st, rng,
+                       ld, d, T, xi, u);
+    return hipGetLastError();
+}
+
+// (N, d) row-major -> (d, ld) parameter-major, zero padding chains N..ld-1
+__global__ void k_nd_to_dn(const double *src, double *dst, int64_t N, int d, int64_t ld)
+{
+    __shared__ double tile[32][33];
+    const int64_t c0 = (int64_t)blockIdx.x * 32;
+    const int p0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int64_t c = c0 + r;
+        const int p = p0 + threadIdx.x;
+        tile[r][threadIdx.x] = (c < N && p < d) ? src[c * d + p] : 0.0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int p = p0 + r;
+        const int64_t c = c0 + threadIdx.x;
+        if (p < d && c < ld) dst[(int64_t)p * ld + c] = tile[threadIdx.x][r];
+    }
+}
+
+hipError_t launch_transpose_nd_to_dn(const double *src, double *dst, int64_t N, int d,
+                                     int64_t ld, hipStream_t st)
+{
+    const dim3 grid((unsigned)((ld + 31) / 32), (unsigned)((d + 31) / 32));
+    hipLaunchKernelGGL(k_nd_to_dn, grid, dim3(32, 8), 0, st, src, dst, N, d, ld);
+    return hipGetLastError();
+}
+
+// `entries` stacked (d, ld) blocks -> (entries, N, d) row-major
+__global__ void k_dn_to_nd(const double *src, double *dst, int64_t N, int d, int64_t ld)
+{
+    __shared__ double tile[32][33];
+    const int64_t e = blockIdx.z;
+    src += e * (int64_t)d * ld;
+    dst += e * N * d;
+    const int64_t c0 = (int64_t)blockIdx.x * 32;
+    const int p0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int p = p0 + r;
+        const int64_t c = c0 + threadIdx.x;
+        tile[r][threadIdx.x] = (p < d && c < N) ? src[(int64_t)p * ld + c] : 0.0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int64_t c = c0 + r;
+        const int p = p0 + threadIdx.x;
+        if (c < N && p < d) dst[c * d + p] = tile[threadIdx.x][r];
+    }
+}
+
+hipError_t launch_transpose_dn_to_nd(const double *src, double *dst, int64_t N, int d,
+                                     int64_t ld, int64_t entries, hipStream_t st)
+{
+    for (int64_t e0 = 0; e0 < entries; e0 += 32768) {
+        const int64_t ne = entries - e0 < 32768 ? entries - e0 : 32768;
+        const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((d + 31) / 32), (unsigned)ne);
+        hipLaunchKernelGGL(k_dn_to_nd, grid, dim3(32, 8), 0, st, src + e0 * (int64_t)d * ld,
+                           dst + e0 * N * d, N, d, ld);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// one v_mfma_f64_16x16x4_f64 with row-major operands (layout self-test)
+__global__ void k_debug_mfma(const double *A, const double *B, const double *C, double *D)
+{
+    const int l = threadIdx.x, m = l & 15, k = l >> 4;
+    double4_t c;
+    c.x = C[(k + 0) * 16 + m];
+    c.y = C[(k + 4) * 16 + m];
+    c.z = C[(k + 8) * 16 + m];
+    c.w = C[(k + 12) * 16 + m];
+    const double4_t d = mfma(A[m * 4 + k], B[k * 16 + m], c);
+    D[(k + 0) * 16 + m] = d.x;
+    D[(k + 4) * 16 + m] = d.y;
+    D[(k + 8) * 16 + m] = d.z;
+    D[(k + 12) * 16 + m] = d.w;
+}
+
+hipError_t launch_debug_mfma(const double *A, const double *B, const double *C, double *D,
+                             hipStream_t st)
+{
+    hipLaunchKernelGGL(k_debug_mfma, dim3(1), dim3(64), 0, st, A, B, C, D);
+    return hipGetLastError();
+}
+
+} // namespace rmh

@@ -1,0 +1,178 @@
+// rmh_mfma.hpp -- the 16-chain wavefront tile shared by the MFMA kernels.
+//
+// One wavefront owns 16 chains.  Lane l = 16*g + cl holds chain cl (of the
+// wave's 16) and the parameters p = 4*s + g, s = 0..S-1 (S = 4*NT, d padded to
+// 16*NT): register s of the lane is parameter 4s+g.  That single layout is at
+// once
+//   * the B operand of v_mfma_f64_16x16x4_f64 for k-step s
+//     (B[k = lane>>4][n = lane&15], one f64 per lane), and
+//   * its C/D layout (col = lane&15, row = (lane>>4) + 4*reg): register r of
+//     output tile i is row 16i + 4r + g, i.e. s = 4i + r,
+// so the result of one triangular contraction feeds the next one without any
+// lane movement, and a chain's state never leaves registers inside a launch.
+//
+// Triangular operands (the Cholesky factor of the proposal, W = L^-1 of the
+// target) live in LDS as "tile images": tile (i, s) holds the 16x4 block
+// rows 16i..16i+15, columns 4s..4s+3 in A-operand lane order
+// (lane l <- M[16i + (l&15)][4s + (l>>4)]), 512 B per tile, so every A fetch is
+// one conflict-free ds_read_b64 at base + 8*lane + imm.
+#pragma once
+#include "rmh_device.hpp"
+
+namespace rmh {
+
+RMH_DEV double4_t mfma(double a, double b, double4_t c)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// raw buffer access: descriptor in SGPRs, 32-bit lane offset, scalar row offset
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+
+RMH_DEV __amdgpu_buffer_rsrc_t rsrc(const void *base, int64_t doubles)
+{
+    const int64_t bytes = doubles * 8;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0,
+                                             bytes > 0xFFFFFFFFLL ? (int)0xFFFFFFFF : (int)bytes,
+                                             0x00020000);
+}
+
+RMH_DEV double buf_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __longlong_as_double((long long)(((uint64_t)v.y << 32) | v.x));
+}
+
+RMH_DEV void buf_store(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, double x)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    v2u_t v;
+    v.x = (unsigned)b;
+    v.y = (unsigned)(b >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+
+template <int NT>
+struct Tile {
+    static constexpr int S = 4 * NT;
+
+    // index of tile (i, s) in a lower-triangular image (s <= 4i+3)
+    static constexpr int lo(int i, int s) { return 2 * i * (i + 1) + s; }
+    // index of tile (i, s) in an upper-triangular image (s >= 4i)
+    static constexpr int up(int i, int s) { return i * S - 2 * i * (i - 1) + (s - 4 * i); }
+
+    // acc[i] += sum_{s <= 4i+3} A_lo(i,s) * B[s]     (A = lower-triangular image)
+    static RMH_DEV void mul_lower(const double *img_lane, const double (&B)[S], double4_t (&acc)[NT])
+    {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int i = s / 4; i < NT; ++i)
+                acc[i] = mfma(img_lane[lo(i, s) * 64], B[s], acc[i]);
+        }
+    }
+
+    // acc[i] += sum_{s >= 4i} A_up(i,s) * B[s]       (A = upper-triangular image)
+    static RMH_DEV void mul_upper(const double *img_lane, const double (&B)[S], double4_t (&acc)[NT])
+    {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int i = 0; i <= s / 4; ++i)
+                acc[i] = mfma(img_lane[up(i, s) * 64], B[s], acc[i]);
+        }
+    }
+
+    static RMH_DEV void unpack(const double4_t (&acc)[NT], double (&v)[S])
+    {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            v[4 * i + 0] = acc[i].x;
+            v[4 * i + 1] = acc[i].y;
+            v[4 * i + 2] = acc[i].z;
+            v[4 * i + 3] = acc[i].w;
+        }
+    }
+
+    static RMH_DEV void pack(const double (&v)[S], double4_t (&acc)[NT])
+    {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            acc[i].x = v[4 * i + 0];
+            acc[i].y = v[4 * i + 1];
+            acc[i].z = v[4 * i + 2];
+            acc[i].w = v[4 * i + 3];
+        }
+    }
+
+    // S normals for this lane: P pairs from the lane's sub-stream; normal m is
+    // coordinate 4m+g, zero beyond d or beyond 2P (rmh-rng v1).
+    static RMH_DEV void normals(Xo &rng, int P, int d, int g, double (&xi)[S])
+    {
+#pragma unroll
+        for (int p = 0; p < S / 2; ++p) {
+            double z0 = 0.0, z1 = 0.0;
+            if (p < P) normal_pair(rng, z0, z1);
+            xi[2 * p] = (4 * (2 * p) + g < d) ? z0 : 0.0;
+            xi[2 * p + 1] = (4 * (2 * p + 1) + g < d) ? z1 : 0.0;
+        }
+    }
+
+    // the accept uniform: one word of sub-stream 0 (lanes g == 0), broadcast to
+    // the chain's four lanes
+    static RMH_DEV double accept_uniform(Xo &rng, int g, int cl)
+    {
+        Xo tmp = rng;
+        const uint64_t r = xo_next(tmp);
+        if (g == 0) rng = tmp;
+        return __shfl(u01(r), cl);
+    }
+
+    // (16*NT, ld) parameter-major state <-> registers.  State arrays are padded
+    // to 16*NT rows (rows >= d hold zeros), so all S accesses are unconditional.
+    // Raw buffer instructions: the descriptor (wave-uniform base) sits in SGPRs,
+    // the row offset 4s*ld*8 is a scalar and the lane part (g*ld + c)*8 is ONE
+    // 32-bit VGPR -- flat/global addressing would cost a 64-bit VGPR pair per row
+    // (hoisted out of the iteration loop: 56 registers for d = 100).
+    static RMH_DEV void load_state(const double *theta, int64_t ld, int64_t c, int g,
+                                   double (&th)[S])
+    {
+        const __amdgpu_buffer_rsrc_t r = rsrc(theta, (int64_t)(4 * S) * ld);
+        const uint32_t voff = (uint32_t)(g * ld + c) * 8u, row = (uint32_t)ld * 32u;
+#pragma unroll
+        for (int s = 0; s < S; ++s) th[s] = buf_load(r, voff, row * (uint32_t)s);
+    }
+
+    static RMH_DEV void store_state(double *theta, int64_t ld, int64_t c, int g,
+                                    const double (&th)[S])
+    {
+        const __amdgpu_buffer_rsrc_t r = rsrc(theta, (int64_t)(4 * S) * ld);
+        const uint32_t voff = (uint32_t)(g * ld + c) * 8u, row = (uint32_t)ld * 32u;
+#pragma unroll
+        for (int s = 0; s < S; ++s) buf_store(r, voff, row * (uint32_t)s, th[s]);
+    }
+
+    // history entries hold 4*ks rows (d rounded up to 4): rows 4s..4s+3 are
+    // written iff s < ks, a wave-uniform test
+    static RMH_DEV void store_rows(double *dst, int64_t ld, int64_t c, int g, int ks,
+                                   const double (&th)[S])
+    {
+        const __amdgpu_buffer_rsrc_t r = rsrc(dst, (int64_t)(4 * ks) * ld);
+        const uint32_t voff = (uint32_t)(g * ld + c) * 8u, row = (uint32_t)ld * 32u;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (s < ks) buf_store(r, voff, row * (uint32_t)s, th[s]);
+    }
+};
+
+// history bookkeeping of Sampler.run (riemann/samplers/sampler.py:49-54):
+// state number e (0 = state on entry) is kept iff e >= nburn and
+// (e - nburn) % nthin == 0, at entry (e - nburn) / nthin.
+RMH_DEV int64_t kept_entry(int64_t e, int64_t nburn, int64_t nthin)
+{
+    if (e < nburn) return -1;
+    const int64_t r = e - nburn;
+    return (r % nthin == 0) ? r / nthin : -1;
+}
+
+} // namespace rmh

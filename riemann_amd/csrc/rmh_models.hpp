@@ -1,0 +1,234 @@
+// rmh_models.hpp -- device Model policies for the MFMA kernels.
+//
+//  GaussModel<NT>  : MultiGaussianDist, riemann/models/gaussian.py:46-58
+//  LogRegModel<NT> : logistic regression plugin against the Model ABC
+//                    (riemann/models/model.py:4-64); not in the reference.
+//
+// A policy provides
+//   lds_doubles(grad)      LDS it needs
+//   setup(lds, args, grad) cooperative fill of the static part (caller syncs)
+//   eval<GRAD>(...)        log posterior (and gradient) of the wave's 16 chains
+//                          in the Tile<NT> register layout; every wave of the
+//                          workgroup must call it (it may contain barriers).
+#pragma once
+#include "rmh_internal.hpp"
+#include "rmh_mfma.hpp"
+
+namespace rmh {
+
+// ------------------------------------------------------------------ Gaussian
+template <int NT>
+struct GaussModel {
+    using Args = GaussArgs;
+    using T = Tile<NT>;
+    static constexpr int S = T::S;
+    static constexpr int kImg = tri_tiles(NT) * 64; // doubles per triangular image
+
+    static size_t lds_doubles(bool grad) { return (size_t)kImg * (grad ? 2 : 1) + 4 * S; }
+
+    static RMH_DEV void setup(double *lds, const Args &m, bool grad)
+    {
+        const int n = kImg, tid = threadIdx.x, nt = blockDim.x;
+        for (int i = tid; i < n; i += nt) lds[i] = m.Wtiles[i];
+        if (grad)
+            for (int i = tid; i < n; i += nt) lds[n + i] = m.WTtiles[i];
+        double *mu = lds + (grad ? 2 * n : n);
+        for (int i = tid; i < 4 * S; i += nt) mu[i] = m.mu_pad[i];
+    }
+
+    // logL = -0.5 (u.u + d log 2pi + logdetC), u = L^-1 (theta - mu)   gaussian.py:49-52
+    // grad = -L^-T u                                                     gaussian.py:54-58
+    // log_prior = 0 (gaussian.py:46-47); log_posterior guard model.py:49-55
+    template <bool GRAD>
+    static RMH_DEV void eval(const double *lds, const Args &m, bool grad_in_lds, int lane,
+                             const double (&th)[S], double &lp, double (&grad)[S],
+                             double (&parts)[2])
+    {
+        const int g = lane >> 4;
+        const double *W = lds + lane;
+        const double *mu = lds + (grad_in_lds ? 2 * kImg : kImg);
+        double uu = 0.0;
+        double4_t acc[NT];
+        if (GRAD) {
+            // u is needed whole (it is the B operand of the W^T product)
+            double y[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) y[s] = th[s] - mu[4 * s + g];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+            T::mul_lower(W, y, acc);
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                uu += acc[i].x * acc[i].x + acc[i].y * acc[i].y + acc[i].z * acc[i].z +
+                      acc[i].w * acc[i].w;
+        } else {
+            // value only: two output tiles in flight (two independent MFMA chains),
+            // theta - mu formed on the fly, so the phase needs ~2 accumulators
+            // instead of NT plus a centred copy of theta
+#pragma unroll
+            for (int i0 = 0; i0 < NT; i0 += 2) {
+                double4_t a0 = double4_t{0.0, 0.0, 0.0, 0.0}, a1 = a0;
+#pragma unroll
+                for (int s = 0; s < 4 * (i0 + 2); ++s) {
+                    if (s >= S) break;
+                    const double y = th[s] - mu[4 * s + g];
+                    if (s < 4 * (i0 + 1)) a0 = mfma(W[T::lo(i0, s) * 64], y, a0);
+                    if (i0 + 1 < NT) a1 = mfma(W[T::lo(i0 + 1 < NT ? i0 + 1 : i0, s) * 64], y, a1);
+                }
+                uu += a0.x * a0.x + a0.y * a0.y + a0.z * a0.z + a0.w * a0.w;
+                if (i0 + 1 < NT) uu += a1.x * a1.x + a1.y * a1.y + a1.z * a1.z + a1.w * a1.w;
+            }
+        }
+        uu = sum4(uu);
+        const double logL = -0.5 * ((uu + m.dlog2pi) + m.logdetC);
+        lp = combine_post(0.0, logL);
+        parts[0] = 0.0;
+        parts[1] = logL;
+        if (GRAD) {
+            double u[S];
+            T::unpack(acc, u);
+            double4_t v[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) v[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+            T::mul_upper(lds + kImg + lane, u, v);
+            T::unpack(v, grad);
+#pragma unroll
+            for (int s = 0; s < S; ++s) grad[s] = -grad[s];
+        }
+    }
+};
+
+// ------------------------------------------------------- logistic regression
+//
+// X streams through LDS in 16-row tiles.  One tile image = 4*NT MFMA tiles of
+// 16 rows x 4 columns (512 B each, zero padded to 16*NT columns) followed by
+// y[16] and w[16] (w = 1 for real rows, 0 for padding rows).  Element (row i,
+// column k) of a row tile sits in tile s = k>>2 at 8-byte slot
+//     (k&3)*16 + (i ^ F),   F = ((s&3)<<2) | (((k&3)>>1)<<1)
+// The XOR makes BOTH operand fetches conflict-free ds_read_b64's of the same
+// image:  eta = X beta   reads A[m=row][k=col]   (lane: row cl, col 4s+g)
+//         g  += X^T r    reads A[m=col][k=row]   (lane: col 16i+cl, row 4r+g)
+// so X is stored, moved and staged exactly once.
+constexpr int kRowTileDoubles(int NT) { return 4 * NT * 64 + 32; }
+
+template <int NT>
+struct LogRegModel {
+    using Args = LogRegArgs;
+    using T = Tile<NT>;
+    static constexpr int S = T::S;
+    static constexpr int RT = kRowTileDoubles(NT); // doubles per row-tile image
+    static constexpr int CH = 2;                   // row tiles per pipeline stage
+
+    static size_t lds_doubles(bool) { return (size_t)2 * CH * RT; }
+    static RMH_DEV void setup(double *, const Args &, bool) {}
+
+    static RMH_DEV void stage_load(const Args &m, int64_t chunk, double2 (&buf)[8], int &nld)
+    {
+        // CH*RT doubles = CH*RT/2 double2's, spread over the workgroup
+        const int total = CH * RT / 2, tid = threadIdx.x, nt = blockDim.x;
+        const int64_t first = chunk * CH;
+        const double2 *src = reinterpret_cast<const double2 *>(m.Ximg + first * RT);
+        const int64_t avail = (m.nrt - first >= CH ? CH : m.nrt - first) * (RT / 2);
+        nld = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = tid + k * nt;
+            if (idx < total) {
+                buf[k] = (idx < avail) ? src[idx] : double2{0.0, 0.0};
+                nld = k + 1;
+            }
+        }
+    }
+
+    static RMH_DEV void stage_store(double *dst, const double2 (&buf)[8])
+    {
+        const int total = CH * RT / 2, tid = threadIdx.x, nt = blockDim.x;
+        double2 *d2 = reinterpret_cast<double2 *>(dst);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = tid + k * nt;
+            if (idx < total) d2[idx] = buf[k];
+        }
+    }
+
+    // one row tile: eta (4*NT MFMAs), link function, gradient (4*NT MFMAs)
+    template <bool GRAD>
+    static RMH_DEV void row_tile(const double *img, const int (&eoff)[4], const int (&goff)[4],
+                                 int g, const double (&th)[S], double &ll, double4_t (&G)[NT])
+    {
+        double4_t eta = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < S; ++s) eta = mfma(img[s * 64 + eoff[s & 3]], th[s], eta);
+        const double *yw = img + 4 * NT * 64;
+        double res[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double e = (r == 0) ? eta.x : (r == 1) ? eta.y : (r == 2) ? eta.z : eta.w;
+            const double yv = yw[4 * r + g], wv = yw[16 + 4 * r + g];
+            const double ex = exp(-fabs(e));
+            const double l1p = log1p(ex);
+            ll += wv * (yv * e - (fmax(e, 0.0) + l1p));
+            const double sg = (e >= 0.0) ? 1.0 / (1.0 + ex) : ex / (1.0 + ex);
+            res[r] = wv * (yv - sg);
+        }
+        if (GRAD) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    G[i] = mfma(img[i * 256 + goff[r]], res[r], G[i]);
+            }
+        }
+    }
+
+    // logL = sum_i y_i eta_i - log(1 + exp(eta_i)),  eta = X beta
+    // logP = -beta.beta / (2 tau2);  grad = X^T (y - sigmoid(eta)) - beta / tau2
+    template <bool GRAD>
+    static RMH_DEV void eval(double *lds, const Args &m, bool, int lane, const double (&th)[S],
+                             double &lp, double (&grad)[S], double (&parts)[2])
+    {
+        const int cl = lane & 15, g = lane >> 4;
+        int eoff[4], goff[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            eoff[k] = g * 16 + (cl ^ ((k << 2) | ((g >> 1) << 1)));
+            const int Fl = ((cl >> 2) << 2) | (((cl & 3) >> 1) << 1);
+            goff[k] = (cl >> 2) * 64 + (cl & 3) * 16 + ((4 * k + g) ^ Fl);
+        }
+        double4_t G[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) G[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+        double ll = 0.0;
+        const int64_t nchunks = (m.nrt + CH - 1) / CH;
+        double2 buf[8];
+        int nld;
+        __syncthreads(); // previous users of the staging buffers are done
+        stage_load(m, 0, buf, nld);
+        stage_store(lds, buf);
+        __syncthreads();
+        for (int64_t c = 0; c < nchunks; ++c) {
+            const double *cur = lds + (c & 1) * (CH * RT);
+            if (c + 1 < nchunks) stage_load(m, c + 1, buf, nld);
+#pragma unroll
+            for (int k = 0; k < CH; ++k) row_tile<GRAD>(cur + k * RT, eoff, goff, g, th, ll, G);
+            if (c + 1 < nchunks) stage_store(lds + ((c + 1) & 1) * (CH * RT), buf);
+            __syncthreads();
+        }
+        ll = sum4(ll);
+        double bb = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) bb += th[s] * th[s];
+        bb = sum4(bb);
+        const double logP = -bb / m.two_tau2;
+        lp = combine_post(logP, ll);
+        parts[0] = logP;
+        parts[1] = ll;
+        if (GRAD) {
+            T::unpack(G, grad);
+#pragma unroll
+            for (int s = 0; s < S; ++s) grad[s] = grad[s] - th[s] * m.inv_tau2;
+        }
+    }
+};
+
+} // namespace rmh

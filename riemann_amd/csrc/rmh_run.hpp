@@ -1,0 +1,275 @@
+// rmh_run.hpp -- the fused Sampler.run kernels over a device Model policy.
+//
+// One launch = T iterations of Sampler.sample (riemann/samplers/sampler.py:72-90)
+// for every chain: propose (proposals/randomwalk.py:21-26 or
+// proposals/hamiltonian.py:13-52,76-91), Model.log_posterior
+// (models/model.py:43-55), accept/reject (sampler.py:83-87), record
+// (sampler.py:62-70 with the [Nburn::Nthin] slice of :53-54).
+//
+// A workgroup of NW wavefronts owns 16*NW chains; LDS holds the (scaled)
+// Cholesky tile image of the proposal and whatever the Model policy needs.
+#pragma once
+#include "rmh_models.hpp"
+
+namespace rmh {
+
+template <int NT>
+RMH_DEV void record(const RunArgs &run, const ChainArgs &ch, int64_t e, int64_t c, int g,
+                    bool active, const double (&th)[4 * NT], double lp)
+{
+    if (!run.h_theta) return;
+    const int64_t k = kept_entry(e, run.nburn, run.nthin);
+    if (k < 0 || !active) return;
+    double *dst = run.h_theta + k * (int64_t)(4 * ch.ks) * ch.ld;
+    Tile<NT>::store_rows(dst, ch.ld, c, g, ch.ks, th);
+    if (g == 0) run.h_logpost[k * ch.ld + c] = lp;
+}
+
+// ------------------------------------------------------------- random walk --
+// The chain's CURRENT state lives in ch.theta (global, L2 resident): it is the
+// C operand of the proposal product at the top of every iteration and is
+// rewritten only on accept, so registers carry one candidate state, not two.
+template <class M, int NW>
+__global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs pr, ChainArgs ch, RunArgs run)
+{
+    constexpr int NT = M::T::S / 4, S = M::T::S;
+    using T = Tile<NT>;
+    extern __shared__ double lds[];
+    double *Limg = lds;
+    double *mlds = lds + tri_tiles(NT) * 64;
+    for (int i = threadIdx.x; i < tri_tiles(NT) * 64; i += blockDim.x) Limg[i] = pr.Ltiles[i];
+    M::setup(mlds, m, false);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, g = lane >> 4;
+    int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const bool active = blk < ch.nblocks;
+    if (!active) blk = ch.nblocks - 1;
+    const int64_t c = blk * 16 + cl;
+    const int64_t slot = blk * 64 + lane;
+
+    double lp = ch.logpost[c];
+    Xo rng = xo_load(ch.rng, ch.nslots, slot);
+
+    for (int64_t t = 0; t <= run.T; ++t) {
+        // the tile images never change, so without this fence LICM hoists their
+        // ds_reads out of the loop and spends the whole register file on them
+        asm volatile("" ::: "memory");
+        double cur[S];
+        T::load_state(ch.theta, ch.ld, c, g, cur);
+        if (t == run.T) { // state number T: record and leave
+            record<NT>(run, ch, t, c, g, active, cur, lp);
+            break;
+        }
+        double xi[S];
+        T::normals(rng, ch.P, ch.d, g, xi);
+        record<NT>(run, ch, t, c, g, active, cur, lp);
+        // theta' = theta + scale * L xi        (randomwalk.py:26; logqratio = 0.0)
+        double4_t acc[NT];
+        T::pack(cur, acc);
+        T::mul_lower(Limg + lane, xi, acc);
+        double thp[S], lpp, dummy[S], parts[2];
+        T::unpack(acc, thp);
+        M::template eval<false>(mlds, m, false, lane, thp, lpp, dummy, parts);
+        const double u = T::accept_uniform(rng, g, cl);
+        const bool acc_ok = mh_accept(lpp, lp, 0.0, u);
+        if (acc_ok) {
+            if (active) T::store_state(ch.theta, ch.ld, c, g, thp);
+            lp = lpp;
+        }
+        if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = acc_ok ? 1 : 0;
+    }
+    if (active) {
+        if (g == 0) ch.logpost[c] = lp;
+        xo_store(ch.rng, ch.nslots, slot, rng);
+    }
+}
+
+// ------------------------------------------------------------ HMC / MALA ----
+// VanillaHMC.propose + leapfrog with M = None.  The gradient at the current
+// state is cached in ch.grad (same point, same function => same bits as the
+// reference's re-evaluation, hamiltonian.py:27), and the last gradient call of
+// the trajectory (:40) is fused with the log_posterior call of sampler.py:82.
+// Current state and cached gradient live in global memory between iterations.
+template <class M, int NW>
+__global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs pr, ChainArgs ch, RunArgs run)
+{
+    constexpr int NT = M::T::S / 4, S = M::T::S;
+    using T = Tile<NT>;
+    extern __shared__ double lds[];
+    M::setup(lds, m, true);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, g = lane >> 4;
+    int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const bool active = blk < ch.nblocks;
+    if (!active) blk = ch.nblocks - 1;
+    const int64_t c = blk * 16 + cl;
+    const int64_t slot = blk * 64 + lane;
+
+    double lp = ch.logpost[c];
+    Xo rng = xo_load(ch.rng, ch.nslots, slot);
+    const double eps = pr.eps, heps = 0.5 * pr.eps;
+
+    for (int64_t t = 0; t <= run.T; ++t) {
+        asm volatile("" ::: "memory"); // no LICM of the LDS tile reads (see k_run_rw)
+        double q[S];
+        T::load_state(ch.theta, ch.ld, c, g, q);
+        record<NT>(run, ch, t, c, g, active, q, lp);
+        if (t == run.T) break;
+        double p[S], gr[S], lpp = 0.0, parts[2];
+        T::normals(rng, ch.P, ch.d, g, p);
+        double k0 = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) k0 += p[s] * p[s];
+        T::load_state(ch.grad, ch.ld, c, g, gr);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            p[s] = p[s] + heps * gr[s];     // hamiltonian.py:27
+            q[s] = q[s] + eps * p[s];       // :30
+        }
+        for (int step = 1; step < pr.nsteps; ++step) { // :34-38
+            asm volatile("" ::: "memory");
+            M::template eval<true>(lds, m, true, lane, q, lpp, gr, parts);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                p[s] = p[s] + eps * gr[s];
+                q[s] = q[s] + eps * p[s];
+            }
+        }
+        M::template eval<true>(lds, m, true, lane, q, lpp, gr, parts);
+        double k1 = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            p[s] = p[s] + heps * gr[s];     // :40
+            k1 += p[s] * p[s];
+        }
+        const double logq = 0.5 * (sum4(k1) - sum4(k0)); // :89
+        const double u = T::accept_uniform(rng, g, cl);
+        const bool acc_ok = mh_accept(lpp, lp, logq, u);
+        if (acc_ok) {
+            if (active) {
+                T::store_state(ch.theta, ch.ld, c, g, q);
+                T::store_state(ch.grad, ch.ld, c, g, gr);
+            }
+            lp = lpp;
+        }
+        if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = acc_ok ? 1 : 0;
+    }
+    if (active) {
+        if (g == 0) ch.logpost[c] = lp;
+        xo_store(ch.rng, ch.nslots, slot, rng);
+    }
+}
+
+// ------------------------------------------------- standalone entry kernels --
+// Model.log_posterior / gradient for the states in ch.theta
+template <class M, bool GRAD, int NW>
+__global__ void __launch_bounds__(64 * NW) k_eval(typename M::Args m, ChainArgs ch, double *lp_out, double *grad_out,
+                                                 double *lprior_out, double *llik_out)
+{
+    constexpr int NT = M::T::S / 4, S = M::T::S;
+    using T = Tile<NT>;
+    extern __shared__ double lds[];
+    M::setup(lds, m, GRAD);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, g = lane >> 4;
+    int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const bool active = blk < ch.nblocks;
+    if (!active) blk = ch.nblocks - 1;
+    const int64_t c = blk * 16 + cl;
+    double th[S], gr[S], lp, parts[2];
+    T::load_state(ch.theta, ch.ld, c, g, th);
+    M::template eval<GRAD>(lds, m, GRAD, lane, th, lp, gr, parts);
+    if (active) {
+        if (g == 0 && lp_out) lp_out[c] = lp;
+        if (g == 0 && lprior_out) lprior_out[c] = parts[0];
+        if (g == 0 && llik_out) llik_out[c] = parts[1];
+        if (GRAD) T::store_state(grad_out, ch.ld, c, g, gr);
+    }
+}
+
+// MetropolisRandomWalk.propose for the states in ch.theta (advances ch.rng)
+template <int NT, int NW>
+__global__ void __launch_bounds__(64 * NW) k_propose_rw(RwArgs pr, ChainArgs ch, double *theta_p)
+{
+    constexpr int S = 4 * NT;
+    using T = Tile<NT>;
+    extern __shared__ double lds[];
+    for (int i = threadIdx.x; i < tri_tiles(NT) * 64; i += blockDim.x) lds[i] = pr.Ltiles[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, g = lane >> 4;
+    const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (blk >= ch.nblocks) return;
+    const int64_t c = blk * 16 + cl, slot = blk * 64 + lane;
+    double th[S], xi[S];
+    T::load_state(ch.theta, ch.ld, c, g, th);
+    Xo rng = xo_load(ch.rng, ch.nslots, slot);
+    T::normals(rng, ch.P, ch.d, g, xi);
+    double4_t acc[NT];
+    T::pack(th, acc);
+    T::mul_lower(lds + lane, xi, acc);
+    T::unpack(acc, th);
+    T::store_state(theta_p, ch.ld, c, g, th);
+    xo_store(ch.rng, ch.nslots, slot, rng);
+}
+
+// VanillaHMC.propose for the states in ch.theta (advances ch.rng)
+template <class M, int NW>
+__global__ void __launch_bounds__(64 * NW) k_propose_hmc(typename M::Args m, HmcArgs pr, ChainArgs ch, double *theta_p,
+                              double *logq_out)
+{
+    constexpr int NT = M::T::S / 4, S = M::T::S;
+    using T = Tile<NT>;
+    extern __shared__ double lds[];
+    M::setup(lds, m, true);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, g = lane >> 4;
+    int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const bool active = blk < ch.nblocks;
+    if (!active) blk = ch.nblocks - 1;
+    const int64_t c = blk * 16 + cl, slot = blk * 64 + lane;
+    double q[S], p[S], gr[S], lpp, parts[2];
+    T::load_state(ch.theta, ch.ld, c, g, q);
+    Xo rng = xo_load(ch.rng, ch.nslots, slot);
+    T::normals(rng, ch.P, ch.d, g, p);
+    double k0 = 0.0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) k0 += p[s] * p[s];
+    const double eps = pr.eps, heps = 0.5 * pr.eps;
+    M::template eval<true>(lds, m, true, lane, q, lpp, gr, parts);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        p[s] = p[s] + heps * gr[s];
+        q[s] = q[s] + eps * p[s];
+    }
+    for (int step = 1; step < pr.nsteps; ++step) {
+        asm volatile("" ::: "memory");
+        M::template eval<true>(lds, m, true, lane, q, lpp, gr, parts);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            p[s] = p[s] + eps * gr[s];
+            q[s] = q[s] + eps * p[s];
+        }
+    }
+    M::template eval<true>(lds, m, true, lane, q, lpp, gr, parts);
+    double k1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        p[s] = p[s] + heps * gr[s];
+        k1 += p[s] * p[s];
+    }
+    const double logq = 0.5 * (sum4(k1) - sum4(k0));
+    if (active) {
+        T::store_state(theta_p, ch.ld, c, g, q);
+        if (g == 0) logq_out[c] = logq;
+        xo_store(ch.rng, ch.nslots, slot, rng);
+    }
+}
+
+} // namespace rmh

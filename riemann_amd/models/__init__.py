@@ -1,0 +1,7 @@
+from .model import Model, DeviceModel
+from .gaussian import MultiGaussianDist
+from .logistic import LogisticRegression
+from .changepoint import ChangepointParams, ChangepointRegression1D
+
+__all__ = ["Model", "DeviceModel", "MultiGaussianDist", "LogisticRegression",
+           "ChangepointParams", "ChangepointRegression1D"]

@@ -1,0 +1,49 @@
+"""VanillaHMC / MALA on the device: /root/reference/riemann/proposals/hamiltonian.py:13-91.
+
+The reference takes an arbitrary Python callable for the gradient
+(hamiltonian.py:60-70).  Here the gradient must come from a device Model, so
+``gradlogpost`` is either that Model or one of its bound gradient methods
+(``model.grad_log_posterior`` / ``model.grad_log_likelihood``), which is how
+the reference's own example passes it (examples/test_randomwalk.py:32-37).
+Unlike the reference module, importing this one does not import matplotlib."""
+import ctypes as C
+
+from .. import _lib
+from ..models.model import DeviceModel
+from .proposal import DeviceProposal
+
+
+class VanillaHMC(DeviceProposal):
+    """Leapfrog proposal with identity mass matrix; logqratio = dK
+    (hamiltonian.py:76-91).  ``.eps``, ``.Nsteps``, ``.M``, ``.chM`` as in the reference."""
+
+    def __init__(self, eps, Nsteps, gradlogpost, M=None):
+        model = getattr(gradlogpost, "__self__", gradlogpost)
+        if not isinstance(model, DeviceModel):
+            raise TypeError("VanillaHMC on the MI355X back end needs the gradient of a device "
+                            "Model: pass the Model or its grad_log_posterior method")
+        if M is not None:
+            raise NotImplementedError("a mass matrix M is not supported by the device kernels yet "
+                                      "(BASELINE configs run with M=None)")
+        if int(Nsteps) != Nsteps or Nsteps < 1:
+            raise _lib.ParameterError("Nsteps must be an integer >= 1")
+        self.Nsteps, self.eps = int(Nsteps), eps
+        self._mgradU = gradlogpost
+        self.M, self.chM = None, None
+        self._model = model
+        self.Npars = model.Npars
+        h = C.c_void_p()
+        _lib.call("rmh_proposal_hmc_create", float(eps), self.Nsteps, self.Npars, C.byref(h))
+        self._h = h
+
+    def _sync(self):
+        _lib.call("rmh_proposal_set_eps", self._h, float(self.eps))
+
+
+class MALA(VanillaHMC):
+    """Metropolis-adjusted Langevin: exactly VanillaHMC(eps, 1, grad) -- theta' =
+    theta + eps^2/2 grad + eps z, and dK equals the Langevin proposal ratio
+    (SURVEY.md 8a-7).  The reference has no such class."""
+
+    def __init__(self, eps, gradlogpost):
+        VanillaHMC.__init__(self, eps, 1, gradlogpost)

@@ -1,0 +1,24 @@
+"""MetropolisRandomWalk on the device: /root/reference/riemann/proposals/randomwalk.py:12-26."""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from .proposal import DeviceProposal
+
+
+class MetropolisRandomWalk(DeviceProposal):
+    """theta' = theta + scale * L xi, xi ~ N(0, I), L = cholesky(C); logqratio = 0
+    (randomwalk.py:17-26).  ``.scale`` and ``.L`` as in the reference."""
+
+    def __init__(self, C_):
+        self.scale = 1.0
+        self.L = np.linalg.cholesky(np.atleast_2d(np.asarray(C_, dtype=np.float64)))
+        self.Npars = self.L.shape[0]
+        h = C.c_void_p()
+        _lib.call("rmh_proposal_rw_create", _lib.as_f64(self.L), self.Npars, float(self.scale),
+                  C.byref(h))
+        self._h = h
+
+    def _sync(self):
+        _lib.call("rmh_proposal_set_scale", self._h, float(self.scale))

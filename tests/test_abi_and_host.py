@@ -1,0 +1,113 @@
+"""CPU-only checks of the product side: the C-ABI library loads and exports
+every symbol include/riemann_hip.h declares, the ctypes table covers them, the
+host logic (stream seeding, error types, plugin API surface) behaves, and the
+package refuses to sample without the device.  No compute call is made."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "riemann_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(rmh_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from riemann_amd import _lib, build
+    so = build.build()
+    lib = ctypes.CDLL(so)
+    names = declared_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), n
+    bound = set(_lib.SIGNATURES) | {"rmh_last_error"}
+    assert bound == set(names), (bound ^ set(names))
+    assert _lib.load() is _lib.load()
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import riemann_amd
+    from riemann_amd import _lib
+    from riemann_amd.models import MultiGaussianDist
+    n = ctypes.c_int(0)
+    rc = _lib.load().rmh_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(RuntimeError):
+        MultiGaussianDist(np.zeros(2), np.eye(2))
+    with pytest.raises(TypeError):      # plain Python plugins are refused, not run on the CPU
+        riemann_amd.Sampler(riemann_amd.Model(), riemann_amd.Proposal(), np.zeros(2))
+
+
+def test_product_does_not_import_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "riemann_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+                assert "rmh_oracle" not in src and "librmh_oracle" not in src, f
+
+
+def test_host_seeding_matches_oracle_stream():
+    from oracle import oracle as orc
+    from riemann_amd.rng import rng_seed_host
+    for seed, N, c0 in ((0, 1, 0), (12345, 37, 7), (2 ** 63 + 5, 200, 2 ** 40)):
+        np.testing.assert_array_equal(rng_seed_host(seed, N, c0), orc.rng_seed(seed, N, chain0=c0))
+
+
+def test_error_types_and_api_surface():
+    import riemann_amd as ra
+    from riemann_amd.models import ChangepointParams, MultiGaussianDist
+    e = ra.ParameterError("boom")
+    assert str(e) == "ParameterError: boom" and isinstance(e, ra.RiemannBaseError)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g7_errors.npz"))
+    with pytest.raises(ra.ParameterError) as ei:     # raised on the host, before any launch
+        MultiGaussianDist(np.zeros(2), np.ones((2, 3)))
+    assert str(ei.value) == str(z["gauss_nonsquare"])
+    with pytest.raises(ra.ParameterError) as ei:
+        MultiGaussianDist(np.zeros(3), np.eye(2))
+    assert str(ei.value) == str(z["gauss_mismatch"])
+    for cls, names in ((ra.Model, ("pack", "unpack", "log_likelihood", "log_prior", "log_posterior",
+                                   "logL", "logP", "__call__")),
+                       (ra.Proposal, ("propose", "adapt")),
+                       (ra.Sampler, ("run", "current_state", "_add_state", "sample"))):
+        for n in names:
+            assert callable(getattr(cls, n)), (cls, n)
+    with pytest.raises(NotImplementedError):
+        ra.Model().log_prior(np.zeros(2))
+    with pytest.raises(NotImplementedError):
+        ra.Proposal().propose(np.zeros(2))
+    p = ChangepointParams([1.5, 2.0], [1.0, 2.0, 3.0], 0.1)
+    v = p.pack()
+    assert v.shape == (6,)
+    q = ChangepointParams.unpack(v)
+    np.testing.assert_array_equal(q.cpx, p.cpx)
+    np.testing.assert_array_equal(q.cpv, p.cpv)
+    with pytest.raises(ValueError):
+        ChangepointParams([1.0], [1.0], 0.1)
+
+
+def test_model_base_log_posterior_guard():
+    """models/model.py:49-55: nan or +-inf in either term -> -inf, batched too."""
+    import riemann_amd as ra
+
+    class M(ra.Model):
+        def log_prior(self, t):
+            return np.asarray(t)[..., 0]
+
+        def log_likelihood(self, t):
+            return np.asarray(t)[..., 1]
+
+    m = M()
+    assert m.log_posterior(np.array([1.0, 2.0])) == 3.0
+    for bad in (np.nan, np.inf, -np.inf):
+        assert m.log_posterior(np.array([bad, 1.0])) == -np.inf
+        assert m(np.array([1.0, bad])) == -np.inf
+    out = m.log_posterior(np.array([[1.0, 2.0], [np.inf, 0.0], [0.0, np.nan]]))
+    np.testing.assert_array_equal(out, [3.0, -np.inf, -np.inf])

@@ -1,0 +1,428 @@
+"""GPU parity tests: the HIP path (through the C ABI / the plugin API) against
+the golden vectors recorded from the reference and against the CPU oracle on
+the same seeded inputs.
+
+Bars (BASELINE.json north_star): accept masks bit-exact; log-densities and
+states within 1e-6 relative -- asserted here at RTOL = 1e-9.  The random
+stream is asserted BIT-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = 1e-9
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import riemann_amd
+    from riemann_amd import _lib
+    _lib.call("rmh_init", 0)
+    return riemann_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def corr100():
+    return 0.1 * np.eye(100) + 0.9 * np.ones((100, 100))
+
+
+def check_run(z, s, sfx=""):
+    np.testing.assert_array_equal(s._chain_accept, z["accept" + sfx])
+    np.testing.assert_allclose(s._chain_thetas, z["thetas" + sfx], rtol=RTOL, atol=1e-12)
+    ref, got = z["logpost" + sfx], s._chain_logpost
+    assert np.array_equal(np.isinf(got), np.isinf(ref))
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(got[fin], ref[fin], rtol=RTOL)
+
+
+# ------------------------------------------------------------ building blocks
+def test_mfma_f64_layout(ra):
+    """A (16x4) B (4x16) + C through one v_mfma_f64_16x16x4_f64, asymmetric data."""
+    from riemann_amd import _lib
+    g = np.random.default_rng(0)
+    A, B, Cm = g.standard_normal((16, 4)), g.standard_normal((4, 16)), g.standard_normal((16, 16))
+    D = np.empty((16, 16))
+    _lib.call("rmh_debug_mfma", A, B, Cm, D)
+    np.testing.assert_allclose(D, A @ B + Cm, rtol=1e-14, atol=1e-14)
+    I4 = np.zeros((16, 4))
+    I4[:4] = np.eye(4)
+    _lib.call("rmh_debug_mfma", I4, B, np.zeros((16, 16)), D)
+    np.testing.assert_array_equal(D[:4], B)   # exact: catches a transposed C/D map
+
+
+def test_rng_stream_bit_exact_vs_fixture(ra):
+    from riemann_amd import _lib
+    z = load("g0_rng")
+    for d in (1, 2, 5, 12, 100):
+        xi, u = np.empty((3, 3, d)), np.empty((3, 3))
+        _lib.call("rmh_debug_rng_stream", int(z["seed"]), int(z["chain0"]), 3, d, 3, xi, u)
+        np.testing.assert_array_equal(xi, z["xi_d%d" % d])
+        np.testing.assert_array_equal(u, z["u_d%d" % d])
+
+
+def test_rng_stream_bit_exact_vs_oracle(ra, orc):
+    from riemann_amd import _lib
+    N, d, T = 1000, 100, 4
+    xi, u = np.empty((T, N, d)), np.empty((T, N))
+    _lib.call("rmh_debug_rng_stream", 77, 123456789, N, d, T, xi, u)
+    exi, eu = orc.rng_stream(orc.rng_seed(77, N, chain0=123456789), d, T)
+    np.testing.assert_array_equal(xi, exi)
+    np.testing.assert_array_equal(u, eu)
+
+
+def test_state_rng_roundtrip_and_seed(ra, orc):
+    from riemann_amd.rng import rng_seed_host
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    s = ra.Sampler(MultiGaussianDist(np.zeros(2), np.eye(2)), MetropolisRandomWalk(np.eye(2)),
+                   np.ones((37, 2)), seed=5, chain0=11)
+    from riemann_amd import _lib
+    st = np.empty((37, 16), dtype=np.uint64)
+    _lib.call("rmh_state_get_rng", s._state, st)
+    np.testing.assert_array_equal(st, orc.rng_seed(5, 37, chain0=11))
+    np.testing.assert_array_equal(st, rng_seed_host(5, 37, 11))
+
+
+# ------------------------------------------------ model evaluations vs oracle
+def test_gaussian_eval_and_grad(ra, orc):
+    from riemann_amd.models import MultiGaussianDist
+    g = np.random.default_rng(1)
+    for d in (1, 2, 17, 40, 100):
+        A = g.standard_normal((d, d))
+        Cov = A @ A.T + d * np.eye(d)
+        mu = g.standard_normal(d)
+        m, o = MultiGaussianDist(mu, Cov), orc.Gaussian(mu, Cov)
+        th = mu + 3 * g.standard_normal((50, d))
+        np.testing.assert_allclose(m.log_posterior(th), o.log_posterior(th), rtol=RTOL)
+        np.testing.assert_allclose(m.log_likelihood(th), o.log_likelihood(th), rtol=RTOL)
+        np.testing.assert_array_equal(m.log_prior(th), 0.0)
+        np.testing.assert_allclose(m.grad_log_likelihood(th), o.grad_log_posterior(th),
+                                   rtol=1e-8, atol=1e-10)
+        assert isinstance(m.log_posterior(th[0]), float)
+
+
+def test_logreg_eval_and_grad(ra, orc):
+    from riemann_amd.models import LogisticRegression
+    from riemann_amd.workloads import logreg_data
+    g = np.random.default_rng(2)
+    for n, d in ((256, 16), (1000, 7), (37, 33), (2000, 100)):
+        X, y = logreg_data(n, d, seed=n)
+        m, o = LogisticRegression(X, y, 100.0), orc.LogReg(X, y, 100.0)
+        th = g.standard_normal((40, d)) * np.array([0.1, 1.0, 5.0, 30.0])[g.integers(0, 4, 40)][:, None]
+        np.testing.assert_allclose(m.log_posterior(th), o.log_posterior(th), rtol=RTOL)
+        np.testing.assert_allclose(m.log_prior(th), o.log_prior(th), rtol=RTOL)
+        np.testing.assert_allclose(m.log_likelihood(th), o.log_likelihood(th), rtol=RTOL)
+        np.testing.assert_allclose(m.grad_log_posterior(th), o.grad_log_posterior(th),
+                                   rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["g5_changepoint_eval", "g5_changepoint_eval_a25"])
+def test_changepoint_eval_vs_reference_fixture(ra, name):
+    from riemann_amd.models import ChangepointRegression1D
+    z = load(name)
+    m = ChangepointRegression1D(z["x"], z["y"], float(z["xmin"]), float(z["xmax"]), float(z["lamb"]),
+                                2 * int(z["k"]), float(z["alpha"]), float(z["beta"]), k=int(z["k"]))
+    th = z["theta"]
+    for fn, key in ((m.log_likelihood, "logL"), (m.log_prior, "logP"), (m.log_posterior, "logpost")):
+        got, ref = fn(th), z[key]
+        assert np.array_equal(np.isinf(got), np.isinf(ref)), key
+        assert np.array_equal(np.sign(got[np.isinf(ref)]), np.sign(ref[np.isinf(ref)])), key
+        fin = np.isfinite(ref)
+        np.testing.assert_allclose(got[fin], ref[fin], rtol=RTOL)
+
+
+def test_propose_vs_oracle(ra, orc):
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk, VanillaHMC
+    g = np.random.default_rng(3)
+    d, N = 100, 70
+    Ct = corr100()
+    th = g.standard_normal((N, d))
+    p = MetropolisRandomWalk(0.05 * Ct)
+    p.scale = 0.7
+    p.seed(9, chain0=4)
+    thp, logq = p.propose(th)
+    st = orc.rng_seed(9, N, chain0=4)
+    ethp, elogq = orc.RandomWalk(0.05 * Ct, 0.7).propose(orc.Gaussian(np.zeros(d), Ct), th, st)
+    np.testing.assert_allclose(thp, ethp, rtol=RTOL, atol=1e-12)
+    np.testing.assert_array_equal(logq, 0.0)
+    np.testing.assert_array_equal(p._rng, st)          # both streams advanced identically
+    m = MultiGaussianDist(np.zeros(d), Ct)
+    for L in (1, 4):
+        h = VanillaHMC(0.2, L, m.grad_log_likelihood)
+        h.seed(10)
+        thp, logq = h.propose(th)
+        ethp, elogq = orc.HMC(0.2, L, d).propose(orc.Gaussian(np.zeros(d), Ct), th, orc.rng_seed(10, N))
+        np.testing.assert_allclose(thp, ethp, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(logq, elogq, rtol=1e-7, atol=1e-9)
+    t1, q1 = p.propose(th[0])                           # single state in, single state out
+    assert t1.shape == (d,) and q1 == 0.0
+
+
+# ------------------------------------------- fixtures recorded from the reference
+def test_g1_gauss2d_rw(ra):
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    z = load("g1_gauss2d_rw")
+    s = ra.Sampler(MultiGaussianDist(z["mu"], z["C"]), MetropolisRandomWalk(z["Cprop"]),
+                   z["theta0"], seed=int(z["seed"]))
+    s.run(64)
+    check_run(z, s)
+
+
+def test_g2_gauss100d_rw(ra):
+    from riemann_amd.models import benchmarks
+    from riemann_amd.proposals import MetropolisRandomWalk
+    z = load("g2_gauss100d_rw")
+    s = ra.Sampler(benchmarks.benchmark_gauss100d_corr,
+                   MetropolisRandomWalk(float(z["prop_factor"]) * corr100()),
+                   z["theta0"], seed=int(z["seed"]))
+    s.run(32)
+    check_run(z, s)
+
+
+@pytest.mark.parametrize("tag", ["mala", "hmc10"])
+def test_g3_gauss100d_hmc(ra, tag):
+    from riemann_amd.models import benchmarks
+    from riemann_amd.proposals import VanillaHMC
+    z = load("g3_gauss100d_" + tag)
+    m = benchmarks.benchmark_gauss100d_corr
+    s = ra.Sampler(m, VanillaHMC(float(z["eps"]), int(z["nsteps"]), m.grad_log_likelihood),
+                   z["theta0"], seed=int(z["seed"]))
+    s.run(16)
+    check_run(z, s)
+
+
+def test_g3_gauss2d_hmc5(ra):
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import VanillaHMC
+    z = load("g3_gauss2d_hmc5")
+    m = MultiGaussianDist(z["mu"], z["C"])
+    s = ra.Sampler(m, VanillaHMC(float(z["eps"]), int(z["nsteps"]), m.grad_log_likelihood),
+                   z["theta0"], seed=int(z["seed"]))
+    s.run(48)
+    check_run(z, s)
+
+
+@pytest.mark.parametrize("tag", ["mala", "hmc10"])
+def test_g4_logreg_small(ra, tag):
+    from riemann_amd.models import LogisticRegression
+    from riemann_amd.proposals import VanillaHMC
+    z = load("g4_logreg256x16_" + tag)
+    m = LogisticRegression(z["X"], z["y"], float(z["tau2"]))
+    s = ra.Sampler(m, VanillaHMC(float(z["eps"]), int(z["nsteps"]), m), z["theta0"],
+                   seed=int(z["seed"]))
+    s.run(32)
+    check_run(z, s)
+
+
+@pytest.mark.parametrize("tag", ["mala", "hmc10"])
+def test_g4_logreg_full_size(ra, tag):
+    from riemann_amd.models import LogisticRegression
+    from riemann_amd.proposals import MALA, VanillaHMC
+    from riemann_amd.workloads import logreg_data
+    z = load("g4_logreg10000x100_" + tag)
+    X, y = logreg_data(int(z["n"]), int(z["d"]), int(z["data_seed"]))
+    m = LogisticRegression(X, y, float(z["tau2"]))
+    p = MALA(float(z["eps"]), m) if tag == "mala" else VanillaHMC(float(z["eps"]), 10, m)
+    s = ra.Sampler(m, p, z["theta0"], seed=int(z["seed"]))
+    s.run(z["accept"].shape[0])
+    check_run(z, s)
+
+
+def cp_model(z):
+    from riemann_amd.models import ChangepointRegression1D
+    return ChangepointRegression1D(z["x"], z["y"], float(z["xmin"]), float(z["xmax"]),
+                                   float(z["lamb"]), 2 * int(z["k"]), float(z["alpha"]),
+                                   float(z["beta"]), k=int(z["k"]))
+
+
+def scaled_rw(z):
+    from riemann_amd.proposals import MetropolisRandomWalk
+    p = MetropolisRandomWalk(np.diag(z["Cdiag"]))
+    p.scale = float(z["scale"])
+    return p
+
+
+def test_g5_changepoint_rw(ra):
+    z = load("g5_changepoint_rw")
+    s = ra.Sampler(cp_model(z), scaled_rw(z), z["theta0"], seed=int(z["seed"]))
+    s.run(64)
+    check_run(z, s)
+
+
+def test_g6_neginf_start_accepts_nan_ratio(ra):
+    z = load("g6_neginf_start")
+    s = ra.Sampler(cp_model(z), scaled_rw(z), z["theta0"], seed=int(z["seed"]))
+    s.run(48)
+    check_run(z, s)
+    assert np.isinf(s._chain_logpost[0, :2]).all() and s._chain_accept[0, :2].all()
+
+
+def test_g6_burn_thin_resume(ra):
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    z = load("g6_burn_thin_resume")
+    s = ra.Sampler(MultiGaussianDist(z["mu"], z["C"]), MetropolisRandomWalk(z["Cprop"]),
+                   z["theta0"], seed=int(z["seed"]))
+    (n0, b0, t0), (n1, b1, t1) = z["runs"]
+    s.run(int(n0), int(b0), int(t0))
+    assert s._chain_thetas.shape[0] == 3                  # run(10,4,3) keeps states 4,7,10
+    np.testing.assert_allclose(s._chain_thetas, z["thetas_run0"], rtol=RTOL)
+    np.testing.assert_allclose(s._chain_logpost, z["logpost_run0"], rtol=RTOL)
+    s.run(int(n1), int(b1), int(t1))                      # continues from the last state
+    assert s._chain_thetas.shape[0] == 6
+    np.testing.assert_allclose(s._chain_thetas, z["thetas_run1"], rtol=RTOL)
+    np.testing.assert_array_equal(s._chain_accept, z["accept_run1"])
+
+
+def test_g7_error_conventions(ra):
+    from riemann_amd import ParameterError
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    z = load("g7_errors")
+    with pytest.raises(ParameterError) as e:
+        MetropolisRandomWalk(np.eye(3)).propose(np.ones(2))
+    assert str(e.value) == str(z["rw_shape"])
+    with pytest.raises(ParameterError) as e:
+        MultiGaussianDist(np.zeros(2), np.ones((2, 3)))
+    assert str(e.value) == str(z["gauss_nonsquare"])
+    with pytest.raises(ParameterError) as e:
+        MultiGaussianDist(np.zeros(3), np.eye(2))
+    assert str(e.value) == str(z["gauss_mismatch"])
+    with pytest.raises(ParameterError):   # model and proposal of different dimension
+        ra.Sampler(MultiGaussianDist(np.zeros(2), np.eye(2)), MetropolisRandomWalk(np.eye(3)),
+                   np.ones(2)).run(1)
+
+
+# ------------------------------------------ larger runs against the CPU oracle
+def oracle_run(orc, model, prop, th0, seed, T, chain0=0):
+    th = np.ascontiguousarray(th0).copy()
+    st = orc.rng_seed(seed, th.shape[0], chain0=chain0)
+    lp = model.log_posterior(th)
+    return orc.run(model, prop, th, lp, st, T)
+
+
+def test_gauss100d_rw_2048_chains(ra, orc):
+    from riemann_amd.models import benchmarks
+    from riemann_amd.proposals import MetropolisRandomWalk
+    Ct = corr100()
+    Cp = (2.38 ** 2 / 100) * Ct
+    th0 = np.random.default_rng(1).standard_normal((2048, 100)) @ np.linalg.cholesky(Ct).T
+    s = ra.Sampler(benchmarks.benchmark_gauss100d_corr, MetropolisRandomWalk(Cp), th0, seed=1)
+    s.run(40)
+    ht, hl, acc = oracle_run(orc, orc.Gaussian(np.zeros(100), Ct), orc.RandomWalk(Cp), th0, 1, 40)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(s._chain_logpost, hl, rtol=RTOL)
+    assert 0.1 < acc.mean() < 0.4
+
+
+def test_ragged_chain_counts_and_single_chain(ra, orc):
+    """N not a multiple of 16 (partial wavefront tile) and the reference's
+    single-chain calling convention."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    g = np.random.default_rng(4)
+    for N, d in ((1, 3), (5, 3), (17, 20), (63, 33), (100, 64)):
+        A = g.standard_normal((d, d))
+        Cov = A @ A.T + d * np.eye(d)
+        th0 = g.standard_normal((N, d))
+        s = ra.Sampler(MultiGaussianDist(np.zeros(d), Cov), MetropolisRandomWalk(0.3 * Cov / d),
+                       th0, seed=N)
+        s.run(25)
+        ht, hl, acc = oracle_run(orc, orc.Gaussian(np.zeros(d), Cov), orc.RandomWalk(0.3 * Cov / d),
+                                 th0, N, 25)
+        np.testing.assert_array_equal(s._chain_accept, acc)
+        np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    s = ra.Sampler(MultiGaussianDist(np.zeros(2), np.eye(2)), MetropolisRandomWalk(np.eye(2)),
+                   np.ones(2), seed=0)
+    s.run(10)
+    assert s._chain_thetas.shape == (11, 2) and s._chain_logpost.shape == (11,)
+    th, lp = s.current_state()
+    assert th.shape == (2,) and isinstance(lp, float)
+    np.testing.assert_array_equal(th, s._chain_thetas[-1])
+    t2, l2 = s.sample()
+    assert s._chain_thetas.shape == (12, 2) and l2 == s._chain_logpost[-1]
+
+
+def test_changepoint_rw_4096_chains(ra, orc):
+    from riemann_amd.models import ChangepointRegression1D
+    from riemann_amd.proposals import MetropolisRandomWalk
+    from riemann_amd.workloads import changepoint_data
+    x, y, truth, cdiag = changepoint_data()
+    g = np.random.default_rng(5)
+    th0 = truth + 0.01 * g.standard_normal((4096, 12))
+    th0[:, :5] = np.sort(th0[:, :5], axis=1)
+    p = MetropolisRandomWalk(np.diag(cdiag))
+    p.scale = 0.1
+    s = ra.Sampler(ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=5), p, th0, seed=3)
+    s.run(60)
+    ht, hl, acc = oracle_run(orc, orc.Changepoint(x, y, 5, 1.0, 3.0, 5.0, 1.0, 1.0),
+                             orc.RandomWalk(np.diag(cdiag), 0.1), th0, 3, 60)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    fin = np.isfinite(hl)
+    assert np.array_equal(np.isfinite(s._chain_logpost), fin)
+    np.testing.assert_allclose(s._chain_logpost[fin], hl[fin], rtol=RTOL)
+
+
+def test_logreg_mala_256_chains(ra, orc):
+    from riemann_amd.models import LogisticRegression
+    from riemann_amd.proposals import MALA
+    from riemann_amd.workloads import logreg_data
+    X, y = logreg_data(2000, 100, seed=2)
+    th0 = 0.05 * np.random.default_rng(6).standard_normal((256, 100))
+    m = LogisticRegression(X, y, 100.0)
+    s = ra.Sampler(m, MALA(0.08, m), th0, seed=8)
+    s.run(12)
+    ht, hl, acc = oracle_run(orc, orc.LogReg(X, y, 100.0), orc.HMC(0.08, 1, 100), th0, 8, 12)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(s._chain_logpost, hl, rtol=RTOL)
+
+
+# --------------------------------- size-independent properties at full chain count
+def test_full_size_sharding_and_resume_invariance(ra):
+    """65 536 chains (cfg2): (i) the chains of a shard started with chain0 = a
+    equal chains [a, b) of the whole job -- the multi-GPU partition is exact;
+    (ii) run(6) + run(6) == run(12); (iii) thinning keeps every 3rd state."""
+    from riemann_amd.models import benchmarks
+    from riemann_amd.proposals import MetropolisRandomWalk
+    N = 65536
+    Ct = corr100()
+    Cp = (2.38 ** 2 / 100) * Ct
+    th0 = np.random.default_rng(1).standard_normal((N, 100)) @ np.linalg.cholesky(Ct).T
+    m, p = benchmarks.benchmark_gauss100d_corr, MetropolisRandomWalk(Cp)
+    whole = ra.Sampler(m, p, th0, seed=1)
+    whole.run(12)
+    th_w, lp_w = whole.current_state()
+    acc_w = whole._chain_accept.copy()
+    a, b = 16384, 32768
+    shard = ra.Sampler(m, p, th0[a:b], seed=1, chain0=a)
+    shard.run(12)
+    th_s, lp_s = shard.current_state()
+    np.testing.assert_array_equal(th_s, th_w[a:b])
+    np.testing.assert_array_equal(lp_s, lp_w[a:b])
+    np.testing.assert_array_equal(shard._chain_accept, acc_w[:, a:b])
+    two = ra.Sampler(m, p, th0, seed=1)
+    two.run(6, record=False)
+    two.run(6, 0, 3)
+    th_t, lp_t = two.current_state()
+    np.testing.assert_array_equal(th_t, th_w)
+    np.testing.assert_array_equal(lp_t, lp_w)
+    np.testing.assert_array_equal(two._chain_thetas, whole._chain_thetas[6::3])
+    assert 0.15 < acc_w.mean() < 0.35

@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Benchmark of the many-chain MH hot path on MI355X (BASELINE.json metric:
+MH chain-iterations/sec aggregate over N chains; ESS/sec).
+
+    python bench.py --gpus 1 --steps K --warmup W [--workload gauss_rw]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one fused ``rmh_run`` launch: ``iters`` MH iterations for every
+chain of this rank, every state recorded into an HBM-resident history
+(the reference records every state, riemann/samplers/sampler.py:69-70).
+Inputs are synthetic (riemann_amd/workloads.py) and resident in HBM before the
+timed region.  Chains shard across ranks by global chain id with no collective
+in the timed region (weak scaling: 65 536 chains per GPU); after it the ranks
+all-gather their final states over RCCL for the pooled diagnostics.
+
+Prints ONE JSON line (rank 0).  Default workload = BASELINE.json configs[1].
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK = 78.6e12   # MI355X FP64 matrix = FP64 vector peak, AMD public spec
+HBM_PEAK = 8.0e12          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+
+
+def workload(name, chains):
+    """-> dict(model, proposal, theta0, flops, bytes, bound, iters, oracle builders, label)"""
+    from riemann_amd import workloads as W
+    from riemann_amd.models import ChangepointRegression1D, LogisticRegression, MultiGaussianDist
+    from riemann_amd.proposals import MALA, MetropolisRandomWalk, VanillaHMC
+    if name == "gauss_rw":      # BASELINE.json configs[1] / SURVEY.md 8d cfg2
+        d = 100
+        Ct = W.corr_gauss_cov(d)
+        Cp = (2.38 ** 2 / d) * Ct
+        th0 = np.random.default_rng(1).standard_normal((chains, d)) @ np.linalg.cholesky(Ct).T
+        return dict(model=MultiGaussianDist(np.zeros(d), Ct), proposal=MetropolisRandomWalk(Cp),
+                    theta0=th0, d=d, iters=100, flops=2 * d * (d + 1) + 4 * d, bytes=8 * (d + 1),
+                    bound="mfma", label="cfg2: 100-d correlated Gaussian, random-walk MH",
+                    omodel=lambda o: o.Gaussian(np.zeros(d), Ct), oprop=lambda o: o.RandomWalk(Cp),
+                    cpu_sample=(65536, 200))
+    if name in ("logreg_mala", "logreg_hmc"):   # configs[2] / configs[3]
+        n, d = 10000, 100
+        X, y = W.logreg_data(n, d, seed=2)
+        m = LogisticRegression(X, y, 100.0)
+        L, eps = (1, 0.175) if name == "logreg_mala" else (10, 0.10)
+        th0 = np.zeros((chains, d))
+        return dict(model=m, proposal=MALA(eps, m) if L == 1 else VanillaHMC(eps, L, m),
+                    theta0=th0, d=d, iters=10 if L == 1 else 2, flops=4 * n * d * L,
+                    bytes=2 * 8 * (2 * d + 1) + 8 * (d + 1), bound="mfma",
+                    label=("cfg3: logistic regression 10000x100, MALA" if L == 1 else
+                           "cfg4: logistic regression 10000x100, HMC L=10"),
+                    omodel=lambda o: o.LogReg(X, y, 100.0), oprop=lambda o: o.HMC(eps, L, d),
+                    cpu_sample=(4096, 4) if L == 1 else (2048, 2))
+    if name == "changepoint_rw":                # configs[4]
+        x, y, truth, cdiag = W.changepoint_data()
+        k, d = 5, 12
+        g = np.random.default_rng(5)
+        th0 = truth + 0.01 * g.standard_normal((chains, d))
+        th0[:, :k] = np.sort(th0[:, :k], axis=1)
+        p = MetropolisRandomWalk(np.diag(cdiag))
+        p.scale = 0.1
+        return dict(model=ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=k), proposal=p,
+                    theta0=th0, d=d, iters=500, flops=900, bytes=8 * (d + 1), bound="hbm",
+                    label="cfg5: changepoint k=5 (n=100), random-walk MH",
+                    omodel=lambda o: o.Changepoint(x, y, k, 1.0, 3.0, 5.0, 1.0, 1.0),
+                    oprop=lambda o: o.RandomWalk(np.diag(cdiag), 0.1), cpu_sample=(65536, 400))
+    raise SystemExit("unknown workload " + name)
+
+
+def cpu_baseline(w, seed):
+    """The oracle (C port of the reference path, OpenMP over chains) on a bounded
+    sample of the same workload, on this box's host cores."""
+    from oracle import oracle as orc
+    N, T = w["cpu_sample"]
+    N = min(N, w["theta0"].shape[0])
+    m, p = w["omodel"](orc), w["oprop"](orc)
+    th = np.ascontiguousarray(w["theta0"][:N]).copy()
+    st = orc.rng_seed(seed, N)
+    lp = m.log_posterior(th)
+    # the one-GPU box share is 16 host cores (task environment); never oversubscribe
+    threads = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0)), 16))
+    orc.run(m, p, th, lp, st, 1, history=False, nthreads=threads)   # warm
+    t0 = time.perf_counter()
+    orc.run(m, p, th, lp, st, T, history=False, nthreads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": N * T / dt, "unit": "chain-iterations/s", "cores": threads, "kind": "port",
+            "sample": "%d chains x %d iterations of the same workload, oracle/rmh_oracle.c "
+                      "(OpenMP over chains), %.1f s" % (N, T, dt)}
+
+
+def tau_estimate(w, seed):
+    """tau_int (min ESS parameter) from an untimed diagnostic run: 256 chains,
+    thinned long trace, on the device."""
+    import riemann_amd as ra
+    from riemann_amd import diagnostics as dg
+    T, thin = (20000, 20) if w["flops"] < 1e6 else (600, 1)
+    s = ra.Sampler(w["model"], w["proposal"], w["theta0"][:256], seed=seed + 1000)
+    s.run(T, T // 5, thin)
+    tau = dg.integrated_time(s._chain_thetas) * thin
+    return float(np.max(tau)), float(s._chain_accept.mean())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="gauss_rw",
+                    choices=["gauss_rw", "logreg_mala", "logreg_hmc", "changepoint_rw"])
+    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
+    ap.add_argument("--iters", type=int, default=0, help="MH iterations per step (0 = workload default)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ess", action="store_true")
+    ap.add_argument("--no-record", action="store_true", help="do not record the history (diagnostic)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import riemann_amd as ra
+    from riemann_amd import _lib
+    _lib.call("rmh_init", local)
+    w = workload(a.workload, a.chains)
+    iters = a.iters or w["iters"]
+    N, d = w["theta0"].shape
+
+    # chains of this rank: global ids [rank*N, (rank+1)*N) -- RNG keyed by global id
+    s = ra.Sampler(w["model"], w["proposal"], w["theta0"], seed=a.seed, chain0=rank * N)
+    hist = C.c_void_p()
+    if not a.no_record:
+        _lib.call("rmh_history_create", s._state, iters + 1, iters, C.byref(hist))
+    w["proposal"]._sync()
+
+    def step():
+        _lib.call("rmh_run", w["model"]._h, w["proposal"]._h, s._state, iters, 0, 1,
+                  hist if hist else None)
+
+    def barrier():
+        _lib.call("rmh_synchronize")
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        # HIP events on the library's stream around each launch; reading them
+        # waits for the launch, which the next launch on the same stream would do anyway
+        ms = C.c_double()
+        _lib.call("rmh_last_run_ms", C.byref(ms), None)
+        kernel_ms.append(ms.value)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # pool the final states of all ranks over RCCL (diagnostics only, untimed)
+    pooled = None
+    if dist is not None:
+        try:
+            import torch
+            th, lp = s.current_state()
+            mine = torch.from_numpy(th).cuda()
+            out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device="cuda")
+            dist.all_gather_into_tensor(out, mine)
+            pooled = {"allgather_bytes_per_rank": int(mine.numel() * 8),
+                      "pooled_mean_abs": float(out.mean(dim=(0, 1)).abs().max().item())}
+        except Exception as e:  # never lose the measurement to the diagnostics
+            pooled = {"allgather_error": repr(e)[:200]}
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    total_iters = world * N * iters * a.steps
+    value = total_iters / dt
+    kms = float(np.mean(kernel_ms))
+    flops = w["flops"] * N * iters
+    bytes_ = (w["bytes"] * (0 if a.no_record else 1)) * N * iters + 16 * (d + 1) * N
+    if w["bound"] == "mfma":
+        ach, peak, unit = flops / (kms * 1e-3) / 1e12, FP64_MFMA_PEAK / 1e12, "TFLOP/s"
+    else:
+        ach, peak, unit = bytes_ / (kms * 1e-3) / 1e9, HBM_PEAK / 1e9, "GB/s"
+    out = {
+        "metric": "MH chain-iterations/sec", "value": value, "unit": "chain-iterations/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": w["label"], "chains_per_gpu": N, "dim": d,
+                   "iterations_per_step": iters, "recorded": (not a.no_record),
+                   "parallelism": "chains sharded by global id, %d rank(s)" % world},
+        "roofline": {"bound": w["bound"], "achieved": ach, "peak": peak, "unit": unit,
+                     "frac": ach / peak, "traffic": None, "kernel_ms": kms,
+                     "hbm_algorithmic_GBps": bytes_ / (kms * 1e-3) / 1e9,
+                     "flops_per_chain_iteration": w["flops"],
+                     "bytes_per_chain_iteration": w["bytes"]},
+    }
+    if pooled:
+        out["pool"] = pooled
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w, a.seed)
+    if not a.no_ess:
+        try:
+            tau, acc = tau_estimate(w, a.seed)
+            out["ess"] = {"tau_int_max": tau, "accept_rate": acc, "ess_per_sec": value / tau,
+                          "estimator": "FFT autocorrelation, Sokal window c=5, 256 chains"}
+        except Exception as e:
+            out["ess"] = {"error": repr(e)[:200]}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

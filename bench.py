@@ -43,7 +43,7 @@ def workload(name, chains):
         Cp = (2.38 ** 2 / d) * Ct
         th0 = np.random.default_rng(1).standard_normal((chains, d)) @ np.linalg.cholesky(Ct).T
         return dict(model=MultiGaussianDist(np.zeros(d), Ct), proposal=MetropolisRandomWalk(Cp),
-                    theta0=th0, d=d, iters=100, flops=2 * d * (d + 1) + 4 * d, bytes=8 * (d + 1),
+                    theta0=th0, d=d, iters=1000, flops=2 * d * (d + 1) + 4 * d, bytes=8 * (d + 1),
                     bound="mfma", label="cfg2: 100-d correlated Gaussian, random-walk MH",
                     omodel=lambda o: o.Gaussian(np.zeros(d), Ct), oprop=lambda o: o.RandomWalk(Cp),
                     cpu_sample=(65536, 200))
@@ -54,7 +54,7 @@ def workload(name, chains):
         L, eps = (1, 0.175) if name == "logreg_mala" else (10, 0.10)
         th0 = np.zeros((chains, d))
         return dict(model=m, proposal=MALA(eps, m) if L == 1 else VanillaHMC(eps, L, m),
-                    theta0=th0, d=d, iters=10 if L == 1 else 2, flops=4 * n * d * L,
+                    theta0=th0, d=d, iters=200 if L == 1 else 100, flops=4 * n * d * L,
                     bytes=2 * 8 * (2 * d + 1) + 8 * (d + 1), bound="mfma",
                     label=("cfg3: logistic regression 10000x100, MALA" if L == 1 else
                            "cfg4: logistic regression 10000x100, HMC L=10"),
@@ -69,11 +69,23 @@ def workload(name, chains):
         p = MetropolisRandomWalk(np.diag(cdiag))
         p.scale = 0.1
         return dict(model=ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=k), proposal=p,
-                    theta0=th0, d=d, iters=500, flops=900, bytes=8 * (d + 1), bound="hbm",
+                    theta0=th0, d=d, iters=2000, flops=900, bytes=8 * (d + 1), bound="hbm",
                     label="cfg5: changepoint k=5 (n=100), random-walk MH",
                     omodel=lambda o: o.Changepoint(x, y, k, 1.0, 3.0, 5.0, 1.0, 1.0),
                     oprop=lambda o: o.RandomWalk(np.diag(cdiag), 0.1), cpu_sample=(65536, 400))
     raise SystemExit("unknown workload " + name)
+
+
+def measured_traffic(name):
+    """HBM bytes per chain-iteration of the run kernel from the committed PMC
+    passes (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in
+    separate rocprofv3 --pmc runs of this same command, FETCH doubled as the
+    gfx950 note of MI355X_MICROARCH.md prescribes), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)[name]["hbm_bytes_per_chain_iteration"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(w, seed):
@@ -128,7 +140,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -161,8 +173,13 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    if dist is not None:    # first collectives build the RCCL communicator: keep that out of the timing
+        import torch
+        for _ in range(3):
+            dist.all_reduce(torch.zeros(1, dtype=torch.float64, device="cuda"), op=dist.ReduceOp.MAX)
+            dist.barrier()
     barrier()
-    kernel_ms = []
+    kernel_ms, step_end = [], []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -171,6 +188,7 @@ def main():
         ms = C.c_double()
         _lib.call("rmh_last_run_ms", C.byref(ms), None)
         kernel_ms.append(ms.value)
+        step_end.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -183,13 +201,14 @@ def main():
     pooled = None
     if dist is not None:
         try:
-            import torch
+            from riemann_amd.distributed import pool_samples, pooled_moments
             th, lp = s.current_state()
-            mine = torch.from_numpy(th).cuda()
-            out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device="cuda")
-            dist.all_gather_into_tensor(out, mine)
-            pooled = {"allgather_bytes_per_rank": int(mine.numel() * 8),
-                      "pooled_mean_abs": float(out.mean(dim=(0, 1)).abs().max().item())}
+            allth = pool_samples(th, world * N, device="cuda")      # RCCL all-gather over xGMI
+            mean, cov = pooled_moments(th, device="cuda")           # RCCL all-reduce
+            pooled = {"allgather_bytes_per_rank": int(th.size * 8),
+                      "pooled_chains": int(allth.shape[0]),
+                      "pooled_mean_abs_max": float(np.abs(mean).max()),
+                      "pooled_var_mean": float(np.diag(cov).mean())}
         except Exception as e:  # never lose the measurement to the diagnostics
             pooled = {"allgather_error": repr(e)[:200]}
 
@@ -206,6 +225,7 @@ def main():
         ach, peak, unit = flops / (kms * 1e-3) / 1e12, FP64_MFMA_PEAK / 1e12, "TFLOP/s"
     else:
         ach, peak, unit = bytes_ / (kms * 1e-3) / 1e9, HBM_PEAK / 1e9, "GB/s"
+    tr = measured_traffic(a.workload)
     out = {
         "metric": "MH chain-iterations/sec", "value": value, "unit": "chain-iterations/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -215,7 +235,9 @@ def main():
                    "iterations_per_step": iters, "recorded": (not a.no_record),
                    "parallelism": "chains sharded by global id, %d rank(s)" % world},
         "roofline": {"bound": w["bound"], "achieved": ach, "peak": peak, "unit": unit,
-                     "frac": ach / peak, "traffic": None, "kernel_ms": kms,
+                     "frac": ach / peak, "traffic": (tr * N * iters if tr else None), "kernel_ms": kms,
+                     "step_wall_ms": [round((b - a_) * 1e3, 3) for a_, b in zip([t0] + step_end, step_end)],
+                     "algorithmic_bytes": bytes_,
                      "hbm_algorithmic_GBps": bytes_ / (kms * 1e-3) / 1e9,
                      "flops_per_chain_iteration": w["flops"],
                      "bytes_per_chain_iteration": w["bytes"]},

@@ -137,7 +137,7 @@ struct rmh_state {
     rmh_model *m = nullptr;
     int64_t N = 0, ld = 0;
     int d = 0, dp = 0, ks = 0, NT = 0;
-    double *theta = nullptr, *grad = nullptr, *logpost = nullptr;
+    double *theta = nullptr, *grad = nullptr, *mom = nullptr, *logpost = nullptr;
     uint64_t *rng = nullptr;
     bool valid = false, grad_valid = false;
 };
@@ -157,6 +157,7 @@ ChainArgs chain_args(const rmh_state *s)
     c.theta = s->theta;
     c.logpost = s->logpost;
     c.grad = s->grad;
+    c.mom = s->mom;
     c.rng = s->rng;
     c.ld = s->ld;
     c.nslots = 4 * s->ld;
@@ -214,6 +215,10 @@ int ensure_grad(rmh_state *s)
         if (rc) return rc;
         RMH_HIP(hipMemsetAsync(s->grad, 0, (size_t)s->dp * s->ld * sizeof(double), g_stream));
     }
+    if (!s->mom) {
+        int rc = dev_alloc(&s->mom, (size_t)s->dp * (s->ld + 64));
+        if (rc) return rc;
+    }
     ChainArgs c = chain_args(s);
     int rc = eval_states(s->m, c, true, nullptr, s->grad, nullptr, nullptr);
     if (rc) return rc;
@@ -229,6 +234,7 @@ struct TmpState {
     {
         (void)hipFree(s.theta);
         (void)hipFree(s.grad);
+        (void)hipFree(s.mom);
         (void)hipFree(s.logpost);
         (void)hipFree(s.rng);
         (void)hipFree(staging);
@@ -383,22 +389,21 @@ int rmh_model_logreg_create(const double *X, const double *y, int64_t n, int d, 
     if (!(tau2 > 0)) return fail(RMH_ERR_PARAM, "logreg: tau2 must be positive");
     const int NT = nt_for_dim(d);
     if (NT < 0) return fail(RMH_ERR_PARAM, "logreg: d > 112 is not supported by the MFMA tile yet");
-    const int64_t nrt = (n + 15) / 16;
-    const int RT = 4 * NT * 64 + 32;
-    std::vector<double> img((size_t)nrt * RT, 0.0);
-    for (int64_t rt = 0; rt < nrt; ++rt) {
-        double *t = &img[(size_t)rt * RT];
-        for (int i = 0; i < 16; ++i) {
-            const int64_t row = rt * 16 + i;
-            if (row >= n) continue;
-            for (int k = 0; k < d; ++k) {
-                const int s = k >> 2, gg = k & 3;
-                const int F = ((s & 3) << 2) | ((gg >> 1) << 1);
-                t[s * 64 + gg * 16 + (i ^ F)] = X[row * d + k];
-            }
-            t[4 * NT * 64 + i] = y[row];
-            t[4 * NT * 64 + 16 + i] = 1.0;
+    // stage images of 2 row tiles each (layout: LogRegModel, rmh_models.hpp)
+    const int64_t nchunks = (n + 31) / 32;
+    const int XT = 256 * NT, CHD = 2 * XT + 128;
+    std::vector<double> img((size_t)nchunks * CHD, 0.0);
+    for (int64_t row = 0; row < n; ++row) {
+        double *ch = &img[(size_t)(row / 32) * CHD];
+        const int k2 = (int)((row / 16) & 1), i = (int)(row & 15);
+        double *t = ch + k2 * XT;
+        for (int k = 0; k < d; ++k) {
+            const int s = k >> 2, gg = k & 3;
+            const int F = ((s & 3) << 2) | ((gg >> 1) << 1);
+            t[s * 64 + gg * 16 + (i ^ F)] = X[row * d + k];
         }
+        ch[2 * XT + k2 * 32 + i] = y[row];
+        ch[2 * XT + k2 * 32 + 16 + i] = 1.0;
     }
     rmh_model *m = new rmh_model;
     m->kind = kLogReg;
@@ -410,8 +415,7 @@ int rmh_model_logreg_create(const double *X, const double *y, int64_t n, int d, 
         return rc;
     }
     m->la.Ximg = m->d_X;
-    m->la.yw = nullptr;
-    m->la.nrt = nrt;
+    m->la.nchunks = nchunks;
     m->la.inv_tau2 = 1.0 / tau2;
     m->la.two_tau2 = 2.0 * tau2;
     *out = m;
@@ -737,6 +741,7 @@ int rmh_state_free(rmh_state_t s)
     if (!s) return RMH_OK;
     (void)hipFree(s->theta);
     (void)hipFree(s->grad);
+    (void)hipFree(s->mom);
     (void)hipFree(s->logpost);
     (void)hipFree(s->rng);
     delete s;

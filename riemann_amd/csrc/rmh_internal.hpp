@@ -19,9 +19,8 @@ struct GaussArgs {
 };
 
 struct LogRegArgs {
-    const double *Ximg;    // per 16-row tile: 4*NT swizzled 16x4 tiles (512 B each)
-    const double *yw;      // per 16-row tile: y[16], w[16]
-    int64_t nrt;           // row tiles
+    const double *Ximg;    // stage images, see LogRegModel (rmh_models.hpp)
+    int64_t nchunks;       // stages of 2 row tiles (32 data rows)
     double inv_tau2;
     double two_tau2;
 };
@@ -42,6 +41,7 @@ struct ChainArgs {
     double *theta;      // (dp, ld), rows >= d are zero
     double *logpost;    // (ld)
     double *grad;       // (dp, ld) cached gradient of the log posterior (HMC), or null
+    double *mom;        // (dp, ld + 64) momentum parking space (HMC), or null
     uint64_t *rng;      // 4 words x nslots
     int64_t ld;         // padded chain count (multiple of 16)
     int64_t nslots;     // 4*ld

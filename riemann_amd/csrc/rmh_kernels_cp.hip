@@ -161,10 +161,12 @@ __global__ void __launch_bounds__(256, 2) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs
     double lp = ch.logpost[c];
     Xo rng = xo_load(ch.rng, ch.nslots, slot);
 
+    int64_t knext = run.nburn, kentry = 0;
     auto rec = [&](int64_t e) {
+        if (e != knext) return;
+        knext += run.nthin;
+        const int64_t k = kentry++;
         if (!run.h_theta) return;
-        const int64_t k = kept_entry(e, run.nburn, run.nthin);
-        if (k < 0) return;
         double *dst = run.h_theta + k * (int64_t)(4 * ch.ks) * ch.ld;
 #pragma unroll
         for (int s = 0; s < S; ++s)

@@ -100,75 +100,64 @@ struct GaussModel {
 
 // ------------------------------------------------------- logistic regression
 //
-// X streams through LDS in 16-row tiles.  One tile image = 4*NT MFMA tiles of
-// 16 rows x 4 columns (512 B each, zero padded to 16*NT columns) followed by
-// y[16] and w[16] (w = 1 for real rows, 0 for padding rows).  Element (row i,
-// column k) of a row tile sits in tile s = k>>2 at 8-byte slot
+// X streams through LDS in stages of CH = 2 row tiles (32 data rows).  One
+// stage image ("chunk") = CH x [4*NT MFMA tiles of 16 rows x 4 columns, 512 B
+// each, zero padded to 16*NT columns], then CH x [y[16], w[16]] (w = 1 for real
+// rows, 0 for padding rows), padded to a whole KiB, so that a stage is moved by
+// 1-KiB global_load_lds pieces (HBM/L2 -> LDS with no VGPR staging).
+// Element (row i, column k) of a row tile sits in tile s = k>>2 at 8-byte slot
 //     (k&3)*16 + (i ^ F),   F = ((s&3)<<2) | (((k&3)>>1)<<1)
 // The XOR makes BOTH operand fetches conflict-free ds_read_b64's of the same
 // image:  eta = X beta   reads A[m=row][k=col]   (lane: row cl, col 4s+g)
 //         g  += X^T r    reads A[m=col][k=row]   (lane: col 16i+cl, row 4r+g)
 // so X is stored, moved and staged exactly once.
-constexpr int kRowTileDoubles(int NT) { return 4 * NT * 64 + 32; }
+constexpr int kLogRegCH = 2;
+constexpr int kChunkDoubles(int NT) { return kLogRegCH * 256 * NT + 128; }
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
 
 template <int NT>
 struct LogRegModel {
     using Args = LogRegArgs;
     using T = Tile<NT>;
     static constexpr int S = T::S;
-    static constexpr int RT = kRowTileDoubles(NT); // doubles per row-tile image
-    static constexpr int CH = 2;                   // row tiles per pipeline stage
+    static constexpr int CH = kLogRegCH;
+    static constexpr int XT = 256 * NT;            // doubles of one row tile's X tiles
+    static constexpr int CHD = kChunkDoubles(NT);  // doubles per stage
+    static constexpr int NP = CHD / 128;           // 1-KiB DMA pieces per stage
 
-    static size_t lds_doubles(bool) { return (size_t)2 * CH * RT; }
+    static size_t lds_doubles(bool) { return (size_t)2 * CHD; }
     static RMH_DEV void setup(double *, const Args &, bool) {}
 
-    static RMH_DEV void stage_load(const Args &m, int64_t chunk, double2 (&buf)[8], int &nld)
+    // asynchronous copy of stage `chunk` into `dst` (LDS): wave w moves pieces
+    // w, w+NW, ...; completion = s_waitcnt vmcnt(0), which __syncthreads() issues
+    static RMH_DEV void stage(const Args &m, int64_t chunk, double *dst)
     {
-        // CH*RT doubles = CH*RT/2 double2's, spread over the workgroup
-        const int total = CH * RT / 2, tid = threadIdx.x, nt = blockDim.x;
-        const int64_t first = chunk * CH;
-        const double2 *src = reinterpret_cast<const double2 *>(m.Ximg + first * RT);
-        const int64_t avail = (m.nrt - first >= CH ? CH : m.nrt - first) * (RT / 2);
-        nld = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int idx = tid + k * nt;
-            if (idx < total) {
-                buf[k] = (idx < avail) ? src[idx] : double2{0.0, 0.0};
-                nld = k + 1;
-            }
-        }
-    }
-
-    static RMH_DEV void stage_store(double *dst, const double2 (&buf)[8])
-    {
-        const int total = CH * RT / 2, tid = threadIdx.x, nt = blockDim.x;
-        double2 *d2 = reinterpret_cast<double2 *>(dst);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int idx = tid + k * nt;
-            if (idx < total) d2[idx] = buf[k];
-        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        const double *src = m.Ximg + chunk * CHD;
+        for (int j = wave; j < NP; j += nw)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(src + j * 128 + lane * 2),
+                                             (lds_void_t *)(dst + j * 128), 16, 0, 0);
     }
 
     // one row tile: eta (4*NT MFMAs), link function, gradient (4*NT MFMAs)
     template <bool GRAD>
-    static RMH_DEV void row_tile(const double *img, const int (&eoff)[4], const int (&goff)[4],
-                                 int g, const double (&th)[S], double &ll, double4_t (&G)[NT])
+    static RMH_DEV void row_tile(const double *img, const double *yw, const int (&eoff)[4],
+                                 const int (&goff)[4], int g, const double (&th)[S], double &ll,
+                                 double4_t (&G)[NT])
     {
         double4_t eta = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < S; ++s) eta = mfma(img[s * 64 + eoff[s & 3]], th[s], eta);
-        const double *yw = img + 4 * NT * 64;
         double res[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double e = (r == 0) ? eta.x : (r == 1) ? eta.y : (r == 2) ? eta.z : eta.w;
             const double yv = yw[4 * r + g], wv = yw[16 + 4 * r + g];
-            const double ex = exp(-fabs(e));
-            const double l1p = log1p(ex);
-            ll += wv * (yv * e - (fmax(e, 0.0) + l1p));
-            const double sg = (e >= 0.0) ? 1.0 / (1.0 + ex) : ex / (1.0 + ex);
+            double lse, sg;
+            logistic_terms(e, lse, sg);
+            ll += wv * (yv * e - lse);
             res[r] = wv * (yv - sg);
         }
         if (GRAD) {
@@ -199,19 +188,15 @@ struct LogRegModel {
 #pragma unroll
         for (int i = 0; i < NT; ++i) G[i] = double4_t{0.0, 0.0, 0.0, 0.0};
         double ll = 0.0;
-        const int64_t nchunks = (m.nrt + CH - 1) / CH;
-        double2 buf[8];
-        int nld;
         __syncthreads(); // previous users of the staging buffers are done
-        stage_load(m, 0, buf, nld);
-        stage_store(lds, buf);
+        stage(m, 0, lds);
         __syncthreads();
-        for (int64_t c = 0; c < nchunks; ++c) {
-            const double *cur = lds + (c & 1) * (CH * RT);
-            if (c + 1 < nchunks) stage_load(m, c + 1, buf, nld);
+        for (int64_t c = 0; c < m.nchunks; ++c) {
+            const double *cur = lds + (c & 1) * CHD;
+            if (c + 1 < m.nchunks) stage(m, c + 1, lds + ((c + 1) & 1) * CHD);
 #pragma unroll
-            for (int k = 0; k < CH; ++k) row_tile<GRAD>(cur + k * RT, eoff, goff, g, th, ll, G);
-            if (c + 1 < nchunks) stage_store(lds + ((c + 1) & 1) * (CH * RT), buf);
+            for (int k = 0; k < CH; ++k)
+                row_tile<GRAD>(cur + k * XT, cur + CH * XT + k * 32, eoff, goff, g, th, ll, G);
             __syncthreads();
         }
         ll = sum4(ll);

@@ -13,22 +13,34 @@
 
 namespace rmh {
 
-template <int NT>
-RMH_DEV void record(const RunArgs &run, const ChainArgs &ch, int64_t e, int64_t c, int g,
-                    bool active, const double (&th)[4 * NT], double lp)
-{
-    if (!run.h_theta) return;
-    const int64_t k = kept_entry(e, run.nburn, run.nthin);
-    if (k < 0 || !active) return;
-    double *dst = run.h_theta + k * (int64_t)(4 * ch.ks) * ch.ld;
-    Tile<NT>::store_rows(dst, ch.ld, c, g, ch.ks, th);
-    if (g == 0) run.h_logpost[k * ch.ld + c] = lp;
-}
+// History bookkeeping of Sampler.run (riemann/samplers/sampler.py:49-54): state
+// number e (0 = state on entry) is kept iff e >= nburn and (e - nburn) % nthin
+// == 0, at entry (e - nburn) / nthin.  States arrive in order, so the next kept
+// number and its entry are tracked incrementally (no 64-bit division per step).
+struct Keep {
+    int64_t next, entry;
+    RMH_DEV explicit Keep(const RunArgs &run) : next(run.nburn), entry(0) {}
+
+    template <int NT>
+    RMH_DEV void record(const RunArgs &run, const ChainArgs &ch, int64_t e, int64_t c, int g,
+                        bool active, const double (&th)[4 * NT], double lp)
+    {
+        if (e != next) return;
+        next += run.nthin;
+        const int64_t k = entry++;
+        if (!run.h_theta || !active) return;
+        double *dst = run.h_theta + k * (int64_t)(4 * ch.ks) * ch.ld;
+        Tile<NT>::store_rows(dst, ch.ld, c, g, ch.ks, th);
+        if (g == 0) run.h_logpost[k * ch.ld + c] = lp;
+    }
+};
 
 // ------------------------------------------------------------- random walk --
-// The chain's CURRENT state lives in ch.theta (global, L2 resident): it is the
-// C operand of the proposal product at the top of every iteration and is
-// rewritten only on accept, so registers carry one candidate state, not two.
+// One wavefront per SIMD (NW = 4): on MI355X v_mfma_f64 and the VALU do not
+// overlap across wavefronts (tools/microbench2.hip), so a second resident wave
+// buys nothing, while one wave gets the whole 512-register file: the chain state,
+// the candidate and the normals all stay in registers and the only HBM traffic
+// of an iteration is the recorded sample.
 template <class M, int NW>
 __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
@@ -49,38 +61,36 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
     const int64_t c = blk * 16 + cl;
     const int64_t slot = blk * 64 + lane;
 
+    double th[S];
+    T::load_state(ch.theta, ch.ld, c, g, th);
     double lp = ch.logpost[c];
     Xo rng = xo_load(ch.rng, ch.nslots, slot);
+    Keep keep(run);
+    keep.record<NT>(run, ch, 0, c, g, active, th, lp);
 
-    for (int64_t t = 0; t <= run.T; ++t) {
+    for (int64_t t = 0; t < run.T; ++t) {
         // the tile images never change, so without this fence LICM hoists their
         // ds_reads out of the loop and spends the whole register file on them
         asm volatile("" ::: "memory");
-        double cur[S];
-        T::load_state(ch.theta, ch.ld, c, g, cur);
-        if (t == run.T) { // state number T: record and leave
-            record<NT>(run, ch, t, c, g, active, cur, lp);
-            break;
-        }
         double xi[S];
         T::normals(rng, ch.P, ch.d, g, xi);
-        record<NT>(run, ch, t, c, g, active, cur, lp);
         // theta' = theta + scale * L xi        (randomwalk.py:26; logqratio = 0.0)
         double4_t acc[NT];
-        T::pack(cur, acc);
+        T::pack(th, acc);
         T::mul_lower(Limg + lane, xi, acc);
         double thp[S], lpp, dummy[S], parts[2];
         T::unpack(acc, thp);
         M::template eval<false>(mlds, m, false, lane, thp, lpp, dummy, parts);
         const double u = T::accept_uniform(rng, g, cl);
         const bool acc_ok = mh_accept(lpp, lp, 0.0, u);
-        if (acc_ok) {
-            if (active) T::store_state(ch.theta, ch.ld, c, g, thp);
-            lp = lpp;
-        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) th[s] = acc_ok ? thp[s] : th[s];
+        lp = acc_ok ? lpp : lp;
         if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = acc_ok ? 1 : 0;
+        keep.record<NT>(run, ch, t + 1, c, g, active, th, lp);
     }
     if (active) {
+        T::store_state(ch.theta, ch.ld, c, g, th);
         if (g == 0) ch.logpost[c] = lp;
         xo_store(ch.rng, ch.nslots, slot, rng);
     }
@@ -109,18 +119,21 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
     const int64_t c = blk * 16 + cl;
     const int64_t slot = blk * 64 + lane;
 
+    // momentum parking column: ch.mom is (dp, ld + 64); the idle waves of the
+    // last workgroup (which shadow its last block) get columns of their own
+    const int64_t cm = active ? c : ch.ld + wave * 16 + cl;
     double lp = ch.logpost[c];
     Xo rng = xo_load(ch.rng, ch.nslots, slot);
     const double eps = pr.eps, heps = 0.5 * pr.eps;
+    Keep keep(run);
 
     for (int64_t t = 0; t <= run.T; ++t) {
         asm volatile("" ::: "memory"); // no LICM of the LDS tile reads (see k_run_rw)
-        double q[S];
+        double p[S], q[S], gr[S], lpp = 0.0, parts[2];
+        if (t < run.T) T::normals(rng, ch.P, ch.d, g, p);
         T::load_state(ch.theta, ch.ld, c, g, q);
-        record<NT>(run, ch, t, c, g, active, q, lp);
+        keep.record<NT>(run, ch, t, c, g, active, q, lp);
         if (t == run.T) break;
-        double p[S], gr[S], lpp = 0.0, parts[2];
-        T::normals(rng, ch.P, ch.d, g, p);
         double k0 = 0.0;
 #pragma unroll
         for (int s = 0; s < S; ++s) k0 += p[s] * p[s];
@@ -130,22 +143,27 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
             p[s] = p[s] + heps * gr[s];     // hamiltonian.py:27
             q[s] = q[s] + eps * p[s];       // :30
         }
-        for (int step = 1; step < pr.nsteps; ++step) { // :34-38
+        // one evaluation site for all Nsteps gradient calls: the last one is
+        // also the log_posterior call of sampler.py:82 and ends with the half kick
+        for (int step = 1; step <= pr.nsteps; ++step) {
+            // the momentum is dead during the evaluation: park it in global memory
+            // (L2) so that the evaluation has the register file to itself
+            T::store_state(ch.mom, ch.ld + 64, cm, g, p);
             asm volatile("" ::: "memory");
             M::template eval<true>(lds, m, true, lane, q, lpp, gr, parts);
+            T::load_state(ch.mom, ch.ld + 64, cm, g, p);
+            const bool last = step == pr.nsteps;
+            const double ek = last ? heps : eps; // :35 / :40
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                p[s] = p[s] + eps * gr[s];
-                q[s] = q[s] + eps * p[s];
+            for (int s = 0; s < S; ++s) p[s] = p[s] + ek * gr[s];
+            if (!last) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) q[s] = q[s] + eps * p[s]; // :37
             }
         }
-        M::template eval<true>(lds, m, true, lane, q, lpp, gr, parts);
         double k1 = 0.0;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            p[s] = p[s] + heps * gr[s];     // :40
-            k1 += p[s] * p[s];
-        }
+        for (int s = 0; s < S; ++s) k1 += p[s] * p[s];
         const double logq = 0.5 * (sum4(k1) - sum4(k0)); // :89
         const double u = T::accept_uniform(rng, g, cl);
         const bool acc_ok = mh_accept(lpp, lp, logq, u);

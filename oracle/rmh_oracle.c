@@ -31,7 +31,7 @@
 #endif
 
 /* ------------------------------------------------------------------------- */
-/* 1. "rmh-rng v1": 4 xoshiro256++ sub-streams per chain                       */
+/* 1. "rmh-rng v2": 4 xoshiro256++ sub-streams per chain                       */
 /* ------------------------------------------------------------------------- */
 /*
  * The reference draws from numpy's process-global MT19937:
@@ -43,10 +43,10 @@
  * vectors are made:
  *
  *   chain c (GLOBAL chain id) owns sub-streams g = 0..3, stream id 4c+g;
- *   every iteration each sub-stream draws P = ceil(ceil(d/4)/2) Box-Muller
- *   pairs; normal number m (0..2P-1) of sub-stream g is coordinate j = 4m+g
- *   (dropped when j >= d); afterwards sub-stream 0 draws one more 64-bit word
- *   for the accept uniform.
+ *   every iteration each sub-stream draws M = ceil(d/4) 64-bit words, one
+ *   standard normal per word (table-driven inverse CDF, below); word m of
+ *   sub-stream g is coordinate j = 4m+g (dropped when j >= d); afterwards
+ *   sub-stream 0 draws one more word for the accept uniform.
  *
  * Four sub-streams because the HIP kernels put a chain on the four lanes
  * {c, c+16, c+32, c+48} of a wavefront (the B-operand layout of
@@ -135,60 +135,41 @@ double orc_log(double x)
     return dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
 }
 
-/* sin(2 pi u), cos(2 pi u) for u in [0,1), defined operation by operation. */
-void orc_sincos2pi(double u, double *sn, double *cs)
+/* ---- one standard normal per 64-bit word: table-driven inverse CDF ----------
+ * (tools/gen_icdf_table.py documents the construction; the table is this
+ * file's own copy, oracle/rmh_icdf_table.h)
+ *   sign = x & 1;  q = x | 1;  r = min(clz(q), ROWS-1);  N = (q << r) | 2^63
+ *   cell = 8 r + N[62:60];  v = 1 + N[59:8] 2^-52;  t = 2 v - 3
+ *   z = Horner_fma(cell polynomial, t), negated when sign is set            */
+#include "rmh_icdf_table.h"
+
+double orc_normal_from_word(u64 x)
 {
-    static const double
-        TWO_PI = 6.283185307179586476925,
-        S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-        S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-        S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10,
-        C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-        C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-        C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    const double q = floor(fma(4.0, u, 0.5));      /* nearest quarter turn, 0..4 */
-    const double r = fma(-0.25, q, u);             /* exact, |r| <= 1/8 */
-    const double x = r * TWO_PI;                   /* |x| <= pi/4 */
-    const double z = x * x;
-    const double ps = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
-    const double sx = fma(x * z, fma(z, ps, S1), x);
-    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
-    const double zz = z * z;
-    const double cx = 1.0 - fma(-zz, pc, 0.5 * z); /* 1 - (z/2 - z^2 pc) */
-    switch (((int)q) & 3) {
-    case 0: *sn = sx;  *cs = cx;  break;
-    case 1: *sn = cx;  *cs = -sx; break;
-    case 2: *sn = -sx; *cs = -cx; break;
-    default: *sn = -cx; *cs = sx; break;
-    }
+    const u64 q = x | 1ULL;
+    int r = __builtin_clzll(q);
+    if (r > RMH_ICDF_ROWS - 1) r = RMH_ICDF_ROWS - 1;
+    const u64 N = (q << r) | 0x8000000000000000ULL;
+    const int j = (int)(N >> 60) & 7;
+    const u64 mant = (N >> 8) & 0x000FFFFFFFFFFFFFULL;
+    const double v = orc_from_bits(0x3FF0000000000000ULL | mant);
+    const double t = fma(2.0, v, -3.0);
+    const double *c = rmh_icdf_table + (size_t)(r * RMH_ICDF_SUB + j) * RMH_ICDF_NC;
+    double z = c[RMH_ICDF_NC - 1];
+    for (int k = RMH_ICDF_NC - 2; k >= 0; k--) z = fma(z, t, c[k]);
+    return (x & 1ULL) ? -z : z;
 }
 
 #define ORC_2M53 0x1p-53
 
-/* one Box-Muller pair from one sub-stream */
-static inline void orc_pair(u64 s[4], double *z0, double *z1)
-{
-    const u64 a = orc_next(s), b = orc_next(s);
-    const double u1 = (double)((a >> 11) + 1) * ORC_2M53; /* (0,1] */
-    const double u2 = (double)(b >> 11) * ORC_2M53;       /* [0,1) */
-    const double r = sqrt(-2.0 * orc_log(u1));
-    double sn, cs;
-    orc_sincos2pi(u2, &sn, &cs);
-    *z0 = r * cs;
-    *z1 = r * sn;
-}
-
-/* d normals for one chain; st = 16 words [g][4]. */
+/* d normals for one chain; st = 16 words [g][4].  Every sub-stream draws
+ * M = ceil(d/4) words; word m of sub-stream g is coordinate 4m+g. */
 void orc_rng_normals(u64 *st, int d, double *xi)
 {
-    const int P = ((d + 3) / 4 + 1) / 2;
+    const int M = (d + 3) / 4;
     for (int g = 0; g < 4; g++)
-        for (int p = 0; p < P; p++) {
-            double z0, z1;
-            orc_pair(st + 4 * g, &z0, &z1);
-            const int j0 = 4 * (2 * p) + g, j1 = 4 * (2 * p + 1) + g;
-            if (j0 < d) xi[j0] = z0;
-            if (j1 < d) xi[j1] = z1;
+        for (int m = 0; m < M; m++) {
+            const double z = orc_normal_from_word(orc_next(st + 4 * g));
+            if (4 * m + g < d) xi[4 * m + g] = z;
         }
 }
 

@@ -12,7 +12,7 @@ import numpy as np
 from .sampling_errors import ParameterError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libriemann_hip.so")
+SO_PATH = os.environ.get("RIEMANN_HIP_LIB") or os.path.join(_HERE, "csrc", "libriemann_hip.so")
 
 RMH_OK, RMH_ERR_PARAM, RMH_ERR_HIP, RMH_ERR_STATE = 0, 1, 2, 3
 

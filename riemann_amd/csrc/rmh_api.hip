@@ -5,6 +5,7 @@
 // hot path happens on the host: a missing GPU is an error, never a fallback.
 #include "../../include/riemann_hip.h"
 #include "rmh_internal.hpp"
+#include "rmh_icdf_table.h"
 
 #include <cmath>
 #include <cstdio>
@@ -23,6 +24,7 @@ hipStream_t g_stream = nullptr;
 hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 int g_last_launches = 0;
 bool g_timed = false;
+double *g_icdf = nullptr; // device copy of the inverse-CDF table, 12-double cell stride
 
 int fail(int code, const std::string &msg)
 {
@@ -165,7 +167,8 @@ ChainArgs chain_args(const rmh_state *s)
     c.d = s->d;
     c.dp = s->dp;
     c.ks = s->ks;
-    c.P = ((s->d + 3) / 4 + 1) / 2;
+    c.M = (s->d + 3) / 4;
+    c.icdf = g_icdf;
     return c;
 }
 
@@ -307,6 +310,19 @@ int rmh_init(int device)
     RMH_HIP(hipStreamCreate(&g_stream));
     RMH_HIP(hipEventCreate(&g_ev0));
     RMH_HIP(hipEventCreate(&g_ev1));
+    {   // inverse-normal-CDF table of the random stream, padded to a 96-byte cell stride
+        static_assert(RMH_ICDF_ROWS == 56 && RMH_ICDF_SUB == 8 && RMH_ICDF_NC == 11, "table shape");
+        // 96-byte cell stride, rows 16 B longer than their cells (kIcdfRowStride, rmh_device.hpp)
+        const int row_stride = RMH_ICDF_SUB * 12 + 2;
+        std::vector<double> pad((size_t)RMH_ICDF_ROWS * row_stride, 0.0);
+        for (int r = 0; r < RMH_ICDF_ROWS; ++r)
+            for (int j = 0; j < RMH_ICDF_SUB; ++j)
+                for (int k = 0; k < RMH_ICDF_NC; ++k)
+                    pad[(size_t)r * row_stride + j * 12 + k] =
+                        rmh_icdf_table[(r * RMH_ICDF_SUB + j) * RMH_ICDF_NC + k];
+        int rc = upload(&g_icdf, pad.data(), pad.size());
+        if (rc) return rc;
+    }
     g_device = device;
     g_init = true;
     return RMH_OK;
@@ -932,7 +948,7 @@ int rmh_debug_rng_stream(uint64_t seed, uint64_t chain0, int64_t N, int d, int T
         return rc;
     }
     hipError_t e = launch_rng_seed(rng, ld, seed, chain0, g_stream);
-    if (e == hipSuccess) e = launch_rng_stream(rng, ld, d, T, dxi, du, g_stream);
+    if (e == hipSuccess) e = launch_rng_stream(rng, ld, d, T, g_icdf, dxi, du, g_stream);
     if (e == hipSuccess)
         e = hipMemcpy2DAsync(xi, (size_t)N * d * 8, dxi, (size_t)ld * d * 8, (size_t)N * d * 8, (size_t)T,
                              hipMemcpyDeviceToHost, g_stream);

@@ -1,13 +1,14 @@
 // rmh_device.hpp -- device-side random stream and elementary functions (gfx950).
 //
-// "rmh-rng v1" (Random stream): chain c owns four xoshiro256++
+// "rmh-rng v2" (Random stream): chain c owns four xoshiro256++
 // sub-streams g = 0..3 (stream id 4c+g).  In the MFMA kernels the four lanes
 // {cl, cl+16, cl+32, cl+48} of a wavefront hold one chain and lane group g owns
 // sub-stream g and the coordinates j = g (mod 4) -- exactly the B-operand
 // layout of v_mfma_f64_16x16x4_f64, so normals are born in the register they
-// are consumed from.  log / sincos are defined operation by operation (explicit
-// fma; the file is compiled with -ffp-contract=off) so that the stream is
-// bit-identical to the CPU oracle's restatement of the same spec.
+// are consumed from.  The inverse-CDF polynomial and the accept test's log are
+// defined operation by operation (explicit fma; the file is compiled with
+// -ffp-contract=off) so that the stream is bit-identical to the CPU oracle's
+// restatement of the same spec.
 //
 // Replaces the process-global numpy generator used by the reference at
 // riemann/proposals/randomwalk.py:25, riemann/proposals/hamiltonian.py:79 and
@@ -205,47 +206,58 @@ RMH_DEV void logistic_terms(double eta, double &lse, double &sg)
     sg = (eta >= 0.0) ? t : e * t;
 }
 
-// sin(2 pi u), cos(2 pi u), u in [0,1)
-RMH_DEV void sincos2pi(double u, double &sn, double &cs)
+// ---- one standard normal per 64-bit word: table-driven inverse CDF (rmh-rng v2)
+//   sign = x & 1;  q = x | 1;  r = min(clz(q), ROWS-1);  N = (q << r) | 2^63
+//   cell = 8 r + N[62:60];  v = 1 + N[59:8] 2^-52;  t = 2 v - 3
+//   z = Horner_fma(cell polynomial of degree 10, t), sign applied by xor
+// No division, square root or trigonometry: 11 fma + ~15 integer operations per
+// normal on top of the xoshiro step (Box-Muller cost ~360 cycles per normal; on
+// this chip f64 MFMA and VALU share the SIMD, so every VALU cycle counts).
+// The table (tools/gen_icdf_table.py, worst error 2.1e-16 relative) is staged in
+// LDS with a 96-byte cell stride: six ds_read_b128 per normal.
+// Rows are 16 B longer than their 8 cells so that the cells of rows r and r+1
+// (3/4 of all draws) fall on disjoint LDS banks.
+constexpr int kIcdfRows = 56, kIcdfSub = 8, kIcdfNC = 11, kIcdfStride = 12;
+constexpr int kIcdfRowStride = kIcdfSub * kIcdfStride + 2;        // doubles
+constexpr int kIcdfDoubles = kIcdfRows * kIcdfRowStride;          // 5488 = 43 904 B
+
+RMH_DEV void icdf_stage(double *lds_tab, const double *glb_tab)
 {
-    constexpr double TWO_PI = 6.283185307179586476925,
-                     S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                     S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                     S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10,
-                     C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                     C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                     C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    const double q = __builtin_floor(fma_(4.0, u, 0.5));
-    const double r = fma_(-0.25, q, u);
-    const double x = r * TWO_PI;
-    const double z = x * x;
-    const double ps = fma_(z, fma_(z, fma_(z, fma_(z, S6, S5), S4), S3), S2);
-    const double sx = fma_(x * z, fma_(z, ps, S1), x);
-    const double pc = fma_(z, fma_(z, fma_(z, fma_(z, fma_(z, C6, C5), C4), C3), C2), C1);
-    const double zz = z * z;
-    const double cx = 1.0 - fma_(-zz, pc, 0.5 * z);
-    const int qi = ((int)q) & 3;
-    const bool swap = qi & 1;
-    const double a = swap ? cx : sx;  // |sin|
-    const double b = swap ? sx : cx;  // |cos|
-    sn = (qi & 2) ? -a : a;
-    cs = ((qi + 1) & 2) ? -b : b;
+    for (int i = threadIdx.x; i < kIcdfDoubles; i += blockDim.x) lds_tab[i] = glb_tab[i];
 }
+
+RMH_DEV double normal_from_word(uint64_t x, const double *tab)
+{
+    const uint64_t q = x | 1ULL;
+    int r = __builtin_clzll(q);
+    r = r > kIcdfRows - 1 ? kIcdfRows - 1 : r;
+    const uint64_t N = (q << r) | 0x8000000000000000ULL;
+    const int j = (int)(N >> 60) & 7;
+    const uint64_t mant = (N >> 8) & 0x000FFFFFFFFFFFFFULL;
+    const double v = __longlong_as_double((long long)(0x3FF0000000000000ULL | mant));
+    const double t = fma_(2.0, v, -3.0);
+    // 16-byte aligned by construction (table base, 784-B rows, 96-B cells): six ds_read_b128
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const d2_t *c = static_cast<const d2_t *>(
+        __builtin_assume_aligned(tab + r * kIcdfRowStride + j * kIcdfStride, 16));
+    const d2_t c01 = c[0], c23 = c[1], c45 = c[2], c67 = c[3], c89 = c[4], cA = c[5];
+    double z = cA.x;
+    z = fma_(z, t, c89.y);
+    z = fma_(z, t, c89.x);
+    z = fma_(z, t, c67.y);
+    z = fma_(z, t, c67.x);
+    z = fma_(z, t, c45.y);
+    z = fma_(z, t, c45.x);
+    z = fma_(z, t, c23.y);
+    z = fma_(z, t, c23.x);
+    z = fma_(z, t, c01.y);
+    z = fma_(z, t, c01.x);
+    return __longlong_as_double(__double_as_longlong(z) ^ (long long)((x & 1ULL) << 63));
+}
+
+RMH_DEV double normal_icdf(Xo &x, const double *tab) { return normal_from_word(xo_next(x), tab); }
 
 constexpr double k2m53 = 0x1p-53;
-
-// one Box-Muller pair from one sub-stream
-RMH_DEV void normal_pair(Xo &x, double &z0, double &z1)
-{
-    const uint64_t a = xo_next(x), b = xo_next(x);
-    const double u1 = (double)((a >> 11) + 1) * k2m53; // (0,1]
-    const double u2 = (double)(b >> 11) * k2m53;       // [0,1)
-    const double r = __builtin_sqrt(-2.0 * log_pos(u1));
-    double sn, cs;
-    sincos2pi(u2, sn, cs);
-    z0 = r * cs;
-    z1 = r * sn;
-}
 
 RMH_DEV double u01(uint64_t r) { return (double)(r >> 11) * k2m53; }
 

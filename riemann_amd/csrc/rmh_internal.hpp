@@ -49,7 +49,8 @@ struct ChainArgs {
     int d;
     int dp;             // rows of theta/grad: 16*NT (MFMA kernels)
     int ks;             // ceil(d/4): history entries hold 4*ks rows
-    int P;              // Box-Muller pairs per sub-stream per iteration
+    int M;              // normals (64-bit words) per sub-stream per iteration: ceil(d/4)
+    const double *icdf; // inverse-normal-CDF table, 96-byte cell stride (rmh_device.hpp)
 };
 
 struct RunArgs {
@@ -104,8 +105,8 @@ hipError_t launch_cp_rw(int k, const CpArgs &m, const RwArgs &p, const ChainArgs
 
 hipError_t launch_rng_seed(uint64_t *rng, int64_t ld, uint64_t seed, uint64_t chain0,
                            hipStream_t st);
-hipError_t launch_rng_stream(uint64_t *rng, int64_t ld, int d, int T, double *xi, double *u,
-                             hipStream_t st);
+hipError_t launch_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const double *icdf,
+                             double *xi, double *u, hipStream_t st);
 hipError_t launch_transpose_nd_to_dn(const double *src, double *dst, int64_t N, int d,
                                      int64_t ld, hipStream_t st);
 hipError_t launch_transpose_dn_to_nd(const double *src, double *dst, int64_t N, int d,

@@ -143,11 +143,13 @@ __global__ void __launch_bounds__(256, 2) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs
     constexpr int D = M::D;
     constexpr int NT = (D + 15) / 16, S = 4 * NT;
     using T = Tile<NT>;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     double *xy = lds;                 // x[n], y[n]
     double *Limg = lds + 2 * m.n;     // tile image of scale*L
+    double *tab = Limg + tri_tiles(NT) * 64;
     for (int i = threadIdx.x; i < 2 * m.n; i += blockDim.x) xy[i] = m.xy[i];
     for (int i = threadIdx.x; i < tri_tiles(NT) * 64; i += blockDim.x) Limg[i] = pr.Ltiles[i];
+    icdf_stage(tab, ch.icdf);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -179,7 +181,7 @@ __global__ void __launch_bounds__(256, 2) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs
         // theta' = theta + scale L xi  (randomwalk.py:26) on the matrix core, in the
         // 4-lanes-per-chain tile; then the chain's lanes exchange their quarters
         double xi[S];
-        T::normals(rng, ch.P, D, g, xi);
+        T::normals(rng, ch.M, D, g, tab, xi);
         double4_t acc[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -226,7 +228,7 @@ __global__ void __launch_bounds__(256) k_cp_eval(CpArgs m, ChainArgs ch, double 
 {
     using M = CpModel<KC>;
     constexpr int D = M::D;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     for (int i = threadIdx.x; i < 2 * m.n; i += blockDim.x) lds[i] = m.xy[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -250,7 +252,7 @@ static hipError_t cp_rw_launch(const CpArgs &m, const RwArgs &p, const ChainArgs
                                const RunArgs &r, hipStream_t st)
 {
     constexpr int D = 2 * KC + 2, NT = (D + 15) / 16;
-    const size_t lds = sizeof(double) * (2 * (size_t)m.n + tri_tiles(NT) * 64);
+    const size_t lds = sizeof(double) * (2 * (size_t)m.n + tri_tiles(NT) * 64 + kIcdfDoubles);
     const int nw = 4;
     const dim3 grid((unsigned)((c.nblocks + nw - 1) / nw));
     hipLaunchKernelGGL(k_cp_rw<KC>, grid, dim3(64 * nw), lds, st, m, p, c, r);

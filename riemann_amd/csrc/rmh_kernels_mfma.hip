@@ -51,8 +51,11 @@ hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const Ch
 {
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
-        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false));
-        constexpr int NW = 4;
+        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false) + kIcdfDoubles);
+        // d > 64: the two tile images fill the LDS of a CU, so one workgroup per CU;
+        // eight waves give every SIMD a second wavefront to cover the s_waitcnt
+        // stalls (LDS table reads of the normals, state/record traffic): +16 %
+        constexpr int NW = (kNT >= 7) ? 8 : 4;
         return launch(k_run_rw<M, NW>, c.nblocks, NW, lds, st, m, p, c, r);
     })
 }
@@ -62,7 +65,7 @@ hipError_t launch_gauss_hmc(int NT, const GaussArgs &m, const HmcArgs &p, const 
 {
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
-        const size_t lds = sizeof(double) * M::lds_doubles(true);
+        const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
         return launch(k_run_hmc<M, 4>, c.nblocks, 4, lds, st, m, p, c, r);
     })
 }
@@ -71,7 +74,7 @@ hipError_t launch_propose_rw(int NT, const RwArgs &p, const ChainArgs &c, double
                              hipStream_t st)
 {
     RMH_NT_DISPATCH(NT, {
-        const size_t lds = sizeof(double) * tri_tiles(kNT) * 64;
+        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + kIcdfDoubles);
         return launch(k_propose_rw<kNT, 4>, c.nblocks, 4, lds, st, p, c, theta_p);
     })
 }
@@ -82,7 +85,7 @@ hipError_t launch_gauss_propose_hmc(int NT, const GaussArgs &m, const HmcArgs &p
 {
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
-        const size_t lds = sizeof(double) * M::lds_doubles(true);
+        const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
         return launch(k_propose_hmc<M, 4>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
     })
 }
@@ -108,7 +111,7 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
 {
     RMH_NT_DISPATCH(NT, {
         using M = LogRegModel<kNT>;
-        const size_t lds = sizeof(double) * M::lds_doubles(true);
+        const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
         return launch(k_run_hmc<M, 4>, c.nblocks, 4, lds, st, m, p, c, r);
     })
 }
@@ -119,7 +122,7 @@ hipError_t launch_logreg_propose_hmc(int NT, const LogRegArgs &m, const HmcArgs 
 {
     RMH_NT_DISPATCH(NT, {
         using M = LogRegModel<kNT>;
-        const size_t lds = sizeof(double) * M::lds_doubles(true);
+        const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
         return launch(k_propose_hmc<M, 4>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
     })
 }
@@ -146,21 +149,22 @@ hipError_t launch_rng_seed(uint64_t *rng, int64_t ld, uint64_t seed, uint64_t ch
 }
 
 // xi (T, ld, d) and u (T, ld) exactly as the fused kernels draw them
-__global__ void k_rng_stream(uint64_t *rng, int64_t ld, int d, int T, double *xi, double *u)
+__global__ void k_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const double *icdf,
+                             double *xi, double *u)
 {
+    extern __shared__ __attribute__((aligned(16))) double tab[];
+    icdf_stage(tab, icdf);
+    __syncthreads();
     const int lane = threadIdx.x & 63, cl = lane & 15, g = lane >> 4;
     const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (blk >= ld / 16) return;
     const int64_t c = blk * 16 + cl, slot = blk * 64 + lane, nslots = 4 * ld;
     Xo x = xo_load(rng, nslots, slot);
-    const int P = ((d + 3) / 4 + 1) / 2;
+    const int M = (d + 3) / 4;
     for (int t = 0; t < T; ++t) {
-        for (int p = 0; p < P; ++p) {
-            double z0, z1;
-            normal_pair(x, z0, z1);
-            const int j0 = 4 * (2 * p) + g, j1 = 4 * (2 * p + 1) + g;
-            if (j0 < d) xi[((int64_t)t * ld + c) * d + j0] = z0;
-            if (j1 < d) xi[((int64_t)t * ld + c) * d + j1] = z1;
+        for (int m = 0; m < M; ++m) {
+            const double z = normal_icdf(x, tab);
+            if (4 * m + g < d) xi[((int64_t)t * ld + c) * d + 4 * m + g] = z;
         }
         const double uu = Tile<1>::accept_uniform(x, g, cl);
         if (g == 0) u[(int64_t)t * ld + c] = uu;
@@ -168,12 +172,12 @@ __global__ void k_rng_stream(uint64_t *rng, int64_t ld, int d, int T, double *xi
     xo_store(rng, nslots, slot, x);
 }
 
-hipError_t launch_rng_stream(uint64_t *rng, int64_t ld, int d, int T, double *xi, double *u,
-                             hipStream_t st)
+hipError_t launch_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const double *icdf,
+                             double *xi, double *u, hipStream_t st)
 {
     const int64_t nblocks = ld / 16;
-    hipLaunchKernelGGL(k_rng_stream, dim3((unsigned)((nblocks + 3) / 4)), dim3(256), 0, st, rng,
-                       ld, d, T, xi, u);
+    hipLaunchKernelGGL(k_rng_stream, dim3((unsigned)((nblocks + 3) / 4)), dim3(256),
+                       sizeof(double) * kIcdfDoubles, st, rng, ld, d, T, icdf, xi, u);
     return hipGetLastError();
 }
 

@@ -105,17 +105,47 @@ struct Tile {
         }
     }
 
-    // S normals for this lane: P pairs from the lane's sub-stream; normal m is
-    // coordinate 4m+g, zero beyond d or beyond 2P (rmh-rng v1).
-    static RMH_DEV void normals(Xo &rng, int P, int d, int g, double (&xi)[S])
+    // S normals for this lane: M = ceil(d/4) words of the lane's sub-stream, word
+    // m is coordinate 4m+g; zero beyond d (rmh-rng v2).  tab = ICDF table in LDS.
+    // Groups of 4 or 8: the xoshiro steps are a serial chain, the four table
+    // evaluations of a group are branch-free so that their LDS latencies and
+    // Horner chains overlap (a single evaluation is latency-bound, ~400 cycles).
+    static RMH_DEV void normals(Xo &rng, int M, int d, int g, const double *tab, double (&xi)[S])
     {
+#ifdef RMH_NORMALS_TWO_PASS
+        uint64_t w[S];
 #pragma unroll
-        for (int p = 0; p < S / 2; ++p) {
-            double z0 = 0.0, z1 = 0.0;
-            if (p < P) normal_pair(rng, z0, z1);
-            xi[2 * p] = (4 * (2 * p) + g < d) ? z0 : 0.0;
-            xi[2 * p + 1] = (4 * (2 * p + 1) + g < d) ? z1 : 0.0;
+        for (int m = 0; m < S; ++m) {
+            w[m] = 0;
+            if (m < M) w[m] = xo_next(rng);
         }
+#pragma unroll
+        for (int m = 0; m < S; ++m) {
+            const double z = normal_from_word(w[m], tab);
+            xi[m] = (4 * m + g < d) ? z : 0.0;
+        }
+#else
+        constexpr int GRP = 4;
+#pragma unroll
+        for (int m0 = 0; m0 < S; m0 += GRP) {
+            if (m0 < M) {
+                uint64_t w[GRP];
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) {
+                    w[k] = 0;
+                    if (m0 + k < M) w[k] = xo_next(rng);
+                }
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) {
+                    const double z = normal_from_word(w[k], tab);
+                    xi[m0 + k] = (4 * (m0 + k) + g < d) ? z : 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) xi[m0 + k] = 0.0;
+            }
+        }
+#endif
     }
 
     // the accept uniform: one word of sub-stream 0 (lanes g == 0), broadcast to
@@ -164,15 +194,5 @@ struct Tile {
             if (s < ks) buf_store(r, voff, row * (uint32_t)s, th[s]);
     }
 };
-
-// history bookkeeping of Sampler.run (riemann/samplers/sampler.py:49-54):
-// state number e (0 = state on entry) is kept iff e >= nburn and
-// (e - nburn) % nthin == 0, at entry (e - nburn) / nthin.
-RMH_DEV int64_t kept_entry(int64_t e, int64_t nburn, int64_t nthin)
-{
-    if (e < nburn) return -1;
-    const int64_t r = e - nburn;
-    return (r % nthin == 0) ? r / nthin : -1;
-}
 
 } // namespace rmh

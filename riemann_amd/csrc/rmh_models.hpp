@@ -24,7 +24,7 @@ struct GaussModel {
     static constexpr int S = T::S;
     static constexpr int kImg = tri_tiles(NT) * 64; // doubles per triangular image
 
-    static size_t lds_doubles(bool grad) { return (size_t)kImg * (grad ? 2 : 1) + 4 * S; }
+    static constexpr __host__ __device__ size_t lds_doubles(bool grad) { return (size_t)kImg * (grad ? 2 : 1) + 4 * S; }
 
     static RMH_DEV void setup(double *lds, const Args &m, bool grad)
     {
@@ -127,7 +127,7 @@ struct LogRegModel {
     static constexpr int CHD = kChunkDoubles(NT);  // doubles per stage
     static constexpr int NP = CHD / 128;           // 1-KiB DMA pieces per stage
 
-    static size_t lds_doubles(bool) { return (size_t)2 * CHD; }
+    static constexpr __host__ __device__ size_t lds_doubles(bool) { return (size_t)2 * CHD; }
     static RMH_DEV void setup(double *, const Args &, bool) {}
 
     // asynchronous copy of stage `chunk` into `dst` (LDS): wave w moves pieces

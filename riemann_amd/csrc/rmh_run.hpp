@@ -36,21 +36,23 @@ struct Keep {
 };
 
 // ------------------------------------------------------------- random walk --
-// One wavefront per SIMD (NW = 4): on MI355X v_mfma_f64 and the VALU do not
-// overlap across wavefronts (tools/microbench2.hip), so a second resident wave
-// buys nothing, while one wave gets the whole 512-register file: the chain state,
-// the candidate and the normals all stay in registers and the only HBM traffic
-// of an iteration is the recorded sample.
+// On MI355X v_mfma_f64 and the VALU do not overlap across wavefronts
+// (tools/microbench2.hip): a second resident wave cannot hide VALU work behind
+// MFMAs, it only covers s_waitcnt stalls.  The chain state, the candidate and the
+// normals all stay in registers (<= 256 at two waves per SIMD) and the only HBM
+// traffic of an iteration is the recorded sample.
 template <class M, int NW>
 __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
     using T = Tile<NT>;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     double *Limg = lds;
     double *mlds = lds + tri_tiles(NT) * 64;
+    double *tab = mlds + M::lds_doubles(false);
     for (int i = threadIdx.x; i < tri_tiles(NT) * 64; i += blockDim.x) Limg[i] = pr.Ltiles[i];
     M::setup(mlds, m, false);
+    icdf_stage(tab, ch.icdf);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -73,7 +75,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
         // ds_reads out of the loop and spends the whole register file on them
         asm volatile("" ::: "memory");
         double xi[S];
-        T::normals(rng, ch.P, ch.d, g, xi);
+        T::normals(rng, ch.M, ch.d, g, tab, xi);
         // theta' = theta + scale * L xi        (randomwalk.py:26; logqratio = 0.0)
         double4_t acc[NT];
         T::pack(th, acc);
@@ -107,8 +109,10 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
     using T = Tile<NT>;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *tab = lds + M::lds_doubles(true);
     M::setup(lds, m, true);
+    icdf_stage(tab, ch.icdf);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -130,7 +134,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
     for (int64_t t = 0; t <= run.T; ++t) {
         asm volatile("" ::: "memory"); // no LICM of the LDS tile reads (see k_run_rw)
         double p[S], q[S], gr[S], lpp = 0.0, parts[2];
-        if (t < run.T) T::normals(rng, ch.P, ch.d, g, p);
+        if (t < run.T) T::normals(rng, ch.M, ch.d, g, tab, p);
         T::load_state(ch.theta, ch.ld, c, g, q);
         keep.record<NT>(run, ch, t, c, g, active, q, lp);
         if (t == run.T) break;
@@ -190,7 +194,7 @@ __global__ void __launch_bounds__(64 * NW) k_eval(typename M::Args m, ChainArgs 
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
     using T = Tile<NT>;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     M::setup(lds, m, GRAD);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -216,8 +220,10 @@ __global__ void __launch_bounds__(64 * NW) k_propose_rw(RwArgs pr, ChainArgs ch,
 {
     constexpr int S = 4 * NT;
     using T = Tile<NT>;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *tab = lds + tri_tiles(NT) * 64;
     for (int i = threadIdx.x; i < tri_tiles(NT) * 64; i += blockDim.x) lds[i] = pr.Ltiles[i];
+    icdf_stage(tab, ch.icdf);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cl = lane & 15, g = lane >> 4;
@@ -227,7 +233,7 @@ __global__ void __launch_bounds__(64 * NW) k_propose_rw(RwArgs pr, ChainArgs ch,
     double th[S], xi[S];
     T::load_state(ch.theta, ch.ld, c, g, th);
     Xo rng = xo_load(ch.rng, ch.nslots, slot);
-    T::normals(rng, ch.P, ch.d, g, xi);
+    T::normals(rng, ch.M, ch.d, g, tab, xi);
     double4_t acc[NT];
     T::pack(th, acc);
     T::mul_lower(lds + lane, xi, acc);
@@ -243,8 +249,10 @@ __global__ void __launch_bounds__(64 * NW) k_propose_hmc(typename M::Args m, Hmc
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
     using T = Tile<NT>;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *tab = lds + M::lds_doubles(true);
     M::setup(lds, m, true);
+    icdf_stage(tab, ch.icdf);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cl = lane & 15, g = lane >> 4;
@@ -255,7 +263,7 @@ __global__ void __launch_bounds__(64 * NW) k_propose_hmc(typename M::Args m, Hmc
     double q[S], p[S], gr[S], lpp, parts[2];
     T::load_state(ch.theta, ch.ld, c, g, q);
     Xo rng = xo_load(ch.rng, ch.nslots, slot);
-    T::normals(rng, ch.P, ch.d, g, p);
+    T::normals(rng, ch.M, ch.d, g, tab, p);
     double k0 = 0.0;
 #pragma unroll
     for (int s = 0; s < S; ++s) k0 += p[s] * p[s];

@@ -1,4 +1,4 @@
-"""Pure-Python restatement of the "rmh-rng v1" stream (oracle/rmh_oracle.c
+"""Pure-Python restatement of the "rmh-rng v2" stream (oracle/rmh_oracle.c
 section 1; DESIGN.md "Random stream"): Python integers for xoshiro256++ and
 exact rational arithmetic for every fma, so that it shares no code and no
 floating-point library with the C oracle or the HIP kernels.  Slow: tests only.
@@ -84,49 +84,46 @@ def spec_log(x):
     return dk * LN2_HI - ((hfsq - fma(s, hfsq + R, dk * LN2_LO)) - f)
 
 
-TWO_PI = 6.283185307179586476925
-S = [-1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
-     2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10]
-Cc = [4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
-      -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11]
+_TABLE = None
 
 
-def spec_sincos2pi(u):
-    q = math.floor(fma(4.0, u, 0.5))
-    r = fma(-0.25, float(q), u)
-    x = r * TWO_PI
-    z = x * x
-    ps = fma(z, fma(z, fma(z, fma(z, S[5], S[4]), S[3]), S[2]), S[1])
-    sx = fma(x * z, fma(z, ps, S[0]), x)
-    pc = fma(z, fma(z, fma(z, fma(z, fma(z, Cc[5], Cc[4]), Cc[3]), Cc[2]), Cc[1]), Cc[0])
-    zz = z * z
-    cx = 1.0 - fma(-zz, pc, 0.5 * z)
-    return [(sx, cx), (cx, -sx), (-sx, -cx), (-cx, sx)][q & 3]
+def table():
+    global _TABLE
+    if _TABLE is None:
+        import os
+        _TABLE = np.load(os.path.join(os.path.dirname(__file__), "golden", "icdf_table.npy"))
+    return _TABLE
 
 
-def pair(s):
-    a, b = nxt(s), nxt(s)
-    u1 = float((a >> 11) + 1) * 2.0 ** -53
-    u2 = float(b >> 11) * 2.0 ** -53
-    r = math.sqrt(-2.0 * spec_log(u1))
-    sn, cs = spec_sincos2pi(u2)
-    return r * cs, r * sn
+def normal_from_word(x):
+    """rmh-rng v2: one standard normal per 64-bit word (tools/gen_icdf_table.py)."""
+    tab = table()
+    rows = tab.shape[0]
+    q = x | 1
+    r = min(64 - q.bit_length(), rows - 1)
+    N = ((q << r) & M64) | (1 << 63)
+    j = (N >> 60) & 7
+    mant = (N >> 8) & 0x000FFFFFFFFFFFFF
+    v = frombits(0x3FF0000000000000 | mant)
+    t = fma(2.0, v, -3.0)
+    c = tab[r, j]
+    z = float(c[-1])
+    for k in range(len(c) - 2, -1, -1):
+        z = fma(z, t, float(c[k]))
+    return -z if (x & 1) else z
 
 
 def stream_normals_uniform(seed, chain, d, T):
     """xi (T,d), u (T,) of GLOBAL chain id `chain`."""
     st = [stream_init(seed, 4 * chain + g) for g in range(4)]
-    P = ((d + 3) // 4 + 1) // 2
+    M = (d + 3) // 4
     xi = np.zeros((T, d))
     u = np.zeros(T)
     for t in range(T):
         for g in range(4):
-            for p in range(P):
-                z0, z1 = pair(st[g])
-                j0, j1 = 4 * (2 * p) + g, 4 * (2 * p + 1) + g
-                if j0 < d:
-                    xi[t, j0] = z0
-                if j1 < d:
-                    xi[t, j1] = z1
+            for m in range(M):
+                z = normal_from_word(nxt(st[g]))
+                if 4 * m + g < d:
+                    xi[t, 4 * m + g] = z
         u[t] = float(nxt(st[0]) >> 11) * 2.0 ** -53
     return xi, u

@@ -159,11 +159,25 @@ def test_oracle_math_close_to_libm():
     got = np.array([orc.olog(x) for x in xs])
     np.testing.assert_allclose(got, np.log(xs), rtol=3e-16, atol=1e-17)
     assert np.isnan(orc.olog(-1.0)) and orc.olog(0.0) == -np.inf and orc.olog(np.inf) == np.inf
-    us = np.concatenate([g.random(2000), [0.0, 0.125, 0.25, 0.5, 0.75, 1 - 2.0 ** -53]])
-    sc = np.array([orc.sincos2pi(u) for u in us])
-    ang = 2 * np.longdouble("3.14159265358979323846264338327950288") * us.astype(np.longdouble)
-    np.testing.assert_allclose(sc[:, 0], np.sin(ang).astype(np.float64), rtol=0, atol=2.3e-16)
-    np.testing.assert_allclose(sc[:, 1], np.cos(ang).astype(np.float64), rtol=0, atol=2.3e-16)
+
+
+def test_inverse_cdf_normals_are_accurate():
+    """z(word) against scipy's normal quantile at the tail probability the word encodes."""
+    from scipy.stats import norm
+    g = np.random.default_rng(1)
+    words = [int(w) for w in g.integers(0, 2 ** 64, 3000, dtype=np.uint64)]
+    words += [1, 2, 3, 2 ** 64 - 1, 2 ** 63, 2 ** 63 + 1, 2 ** 40 + 5, 2 ** 12, 2 ** 7 + 1, 0]
+    for w in words:
+        z = orc.normal_from_word(w)
+        q = w | 1
+        r = min(64 - q.bit_length(), 55)
+        N = ((q << r) & (2 ** 64 - 1)) | 2 ** 63
+        p = (N >> 8) / 2.0 ** 55 * 2.0 ** (-2 - r)          # = 2^(-2-r) (1 + j/8 + mant 2^-55)
+        ref = norm.isf(p)
+        assert abs(abs(z) - ref) <= 4e-15 * max(1.0, ref), (w, z, ref)
+        assert (z < 0) == bool(w & 1) or z == 0
+    # symmetric by construction: the sign is bit 0, which the magnitude ignores
+    assert orc.normal_from_word(12345 * 2) == -orc.normal_from_word(12345 * 2 + 1)
 
 
 def test_rng_matches_pure_python_restatement():

@@ -3,6 +3,7 @@
 //   one Box-Muller pair of the rmh-rng stream, fp64 FMA throughput,
 //   each at 1 and 2 waves per SIMD.   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
 #include "../riemann_amd/csrc/rmh_mfma.hpp"
+#include "../riemann_amd/csrc/rmh_icdf_table.h"
 #include <cstdio>
 #include <vector>
 using namespace rmh;
@@ -25,15 +26,19 @@ __global__ void k_mfma(double *out, int iters)
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (double)(t1 - t0) / (16.0 * iters);
 }
 
+__device__ double g_tab[kIcdfDoubles];
+
 __global__ void k_pair(double *out, int iters)
 {
+    __shared__ double tab[kIcdfDoubles];
+    icdf_stage(tab, g_tab);
+    __syncthreads();
     Xo x;
     xo_init(x, 1, threadIdx.x + blockIdx.x * blockDim.x);
     double s = 0;
     long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
-        double z0, z1;
-        normal_pair(x, z0, z1);
+        const double z0 = normal_icdf(x, tab), z1 = normal_icdf(x, tab);
         s += z0 * z1;
     }
     long long t1 = clock64();
@@ -63,13 +68,15 @@ __global__ void k_mix(double *out, int iters)
 {
     double4_t acc[4];
     for (int i = 0; i < 4; ++i) acc[i] = double4_t{0, 0, 0, 0};
+    __shared__ double tab[kIcdfDoubles];
+    icdf_stage(tab, g_tab);
+    __syncthreads();
     Xo x;
     xo_init(x, 1, threadIdx.x);
     double a = threadIdx.x * 1e-3, s = 0;
     long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
-        double z0, z1;
-        normal_pair(x, z0, z1);
+        const double z0 = normal_icdf(x, tab), z1 = normal_icdf(x, tab);
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k % 4] = mfma(a, s, acc[k % 4]);
         s += z0 * z1;
@@ -100,13 +107,19 @@ double run(K k, int threads, int iters, double *d)
 int main()
 {
     double *d; hipMalloc(&d, 256 * 1024 * 8);
+    {
+        std::vector<double> pad(kIcdfDoubles, 0.0);
+        for (int c = 0; c < 448; ++c)
+            for (int k = 0; k < 11; ++k) pad[(c / 8) * kIcdfRowStride + (c % 8) * 12 + k] = rmh_icdf_table[c * 11 + k];
+        hipMemcpyToSymbol(HIP_SYMBOL(g_tab), pad.data(), pad.size() * 8);
+    }
     const int it = 20000;
     for (int threads : {256, 512}) {
         printf("== %d threads/WG, 1 WG/CU (%d wave(s)/SIMD)\n", threads, threads / 256);
         printf("mfma f64 16x16x4, 1 accumulator (dependent):\n"); run(k_mfma<1>, threads, it, d);
         printf("mfma f64 16x16x4, 2 accumulators:\n"); run(k_mfma<2>, threads, it, d);
         printf("mfma f64 16x16x4, 4 accumulators:\n"); run(k_mfma<4>, threads, it, d);
-        printf("box-muller pair (2 normals):\n"); run(k_pair, threads, it, d);
+        printf("2 inverse-CDF normals (rmh-rng v2):\n"); run(k_pair, threads, it, d);
         printf("v_fma_f64, 8 independent chains:\n"); run(k_fma, threads, it, d);
         printf("1 pair + 16 mfma per iteration (same wave):\n"); run(k_mix, threads, it / 4, d);
     }

@@ -46,14 +46,10 @@ __global__ void __launch_bounds__(512) k(double *out, int iters)
                 for (int q = 0; q < 8; ++q) s ^= xo_next(x);
             }
             r = (double)s;
-        } else { // box-muller pair
+        } else { // integer + fma mix
             Xo x;
             xo_init(x, 1, threadIdx.x);
-            for (int it = 0; it < iters; ++it) {
-                double z0, z1;
-                normal_pair(x, z0, z1);
-                r += z0 * z1;
-            }
+            for (int it = 0; it < iters; ++it) r = __builtin_fma(r, 0.5, (double)(xo_next(x) >> 40));
         }
     }
     out[blockIdx.x * 512 + threadIdx.x] = r;
@@ -78,7 +74,7 @@ int main()
 {
     double *d; hipMalloc(&d, 256 * 512 * 8);
     const int it = 10000;
-    const char *names[4] = {"f64 fma x128", "f32 fma x256", "xoshiro x8", "box-muller pair"};
+    const char *names[4] = {"f64 fma x128", "f32 fma x256", "xoshiro x8", "xoshiro + fma"};
     float m = run(k<0, true, false>, it, d);
     printf("mfma alone (16/iter): %.3f ms\n", m);
 #define ROW(K) { float v = run(k<K, false, true>, it, d), b = run(k<K, true, true>, it, d); \

@@ -6,6 +6,7 @@
 #include "../../include/riemann_hip.h"
 #include "rmh_internal.hpp"
 #include "rmh_icdf_table.h"
+#include "rmh_logistic_table.h"
 
 #include <cmath>
 #include <cstdio>
@@ -25,6 +26,7 @@ hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 int g_last_launches = 0;
 bool g_timed = false;
 double *g_icdf = nullptr; // device copy of the inverse-CDF table, 12-double cell stride
+double *g_logi = nullptr; // device copy of the logistic link-function table
 
 int fail(int code, const std::string &msg)
 {
@@ -322,6 +324,8 @@ int rmh_init(int device)
                         rmh_icdf_table[(r * RMH_ICDF_SUB + j) * RMH_ICDF_NC + k];
         int rc = upload(&g_icdf, pad.data(), pad.size());
         if (rc) return rc;
+        static_assert(RMH_LOGI_NI == 150 && RMH_LOGI_W == 4 && RMH_LOGI_NC == 10, "table shape");
+        if ((rc = upload(&g_logi, rmh_logistic_table, sizeof(rmh_logistic_table) / sizeof(double)))) return rc;
     }
     g_device = device;
     g_init = true;
@@ -415,7 +419,7 @@ int rmh_model_logreg_create(const double *X, const double *y, int64_t n, int d, 
         double *t = ch + k2 * XT;
         for (int k = 0; k < d; ++k) {
             const int s = k >> 2, gg = k & 3;
-            const int F = ((s & 3) << 2) | ((gg >> 1) << 1);
+            const int F = ((s & 3) << 2) | gg;
             t[s * 64 + gg * 16 + (i ^ F)] = X[row * d + k];
         }
         ch[2 * XT + k2 * 32 + i] = y[row];
@@ -432,6 +436,8 @@ int rmh_model_logreg_create(const double *X, const double *y, int64_t n, int d, 
     }
     m->la.Ximg = m->d_X;
     m->la.nchunks = nchunks;
+    m->la.ks = (d + 3) / 4;
+    m->la.logi = g_logi;
     m->la.inv_tau2 = 1.0 / tau2;
     m->la.two_tau2 = 2.0 * tau2;
     *out = m;

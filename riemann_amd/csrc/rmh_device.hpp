@@ -194,7 +194,9 @@ RMH_DEV double log_1to2(double u)
 }
 
 // for one linear predictor eta: lse = log(1 + exp(eta)) and sg = sigmoid(eta)
-RMH_DEV void logistic_terms(double eta, double &lse, double &sg)
+// (closed-form version: exp, reciprocal, log; ~63 f64 operations -- kept as the
+// reference form of the table version below)
+RMH_DEV void logistic_terms_closed(double eta, double &lse, double &sg)
 {
     const double a = __builtin_fabs(eta);
     const double e = exp_neg(a);          // in [0, 1]
@@ -204,6 +206,59 @@ RMH_DEV void logistic_terms(double eta, double &lse, double &sg)
     const double l1p = fma_(lo, t, log_1to2(u)); // log1p(e)
     lse = ((eta > 0.0) ? eta : 0.0) + l1p;
     sg = (eta >= 0.0) ? t : e * t;
+}
+
+// Table version (tools/gen_logistic_table.py): |eta| in [0, 37.5) is cut into 150
+// intervals of width 1/4, each with two degree-9 polynomials in t = 2 frac(4|eta|) - 1:
+//   f = log1p(exp(-|eta|)),  s = sigmoid(-|eta|);  worst relative error 2.1e-16.
+// 20 fma + ~10 other operations and ten ds_read_b128 instead of exp + rcp + log:
+// on this chip every VALU cycle is taken from the f64 MFMA pipe.  Beyond 37.5 both
+// functions are < 6e-17 and are taken at the table edge.  tab = table in LDS.
+constexpr int kLogiNI = 150, kLogiNC = 10, kLogiDoubles = kLogiNI * 2 * kLogiNC;
+
+// split in two so that a kernel can put independent MFMAs between the gather and
+// its first use (one wave per SIMD has nothing else to cover the LDS latency with)
+struct LogiGather {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    d2_t c[10];
+    double t;
+};
+
+RMH_DEV void logistic_gather(double eta, const double *tab, LogiGather &q)
+{
+    double a = __builtin_fabs(eta);
+    a = (a < 37.4999999) ? a : 37.4999999;
+    const double u = a * 4.0;
+    const int idx = (int)u;
+    q.t = fma_(2.0, u - __builtin_floor(u), -1.0);
+    const LogiGather::d2_t *c = static_cast<const LogiGather::d2_t *>(
+        __builtin_assume_aligned(tab + idx * (2 * kLogiNC), 16));
+#pragma unroll
+    for (int k = 0; k < 10; ++k) q.c[k] = c[k];
+}
+
+RMH_DEV void logistic_finish(double eta, const LogiGather &q, double &lse, double &sg)
+{
+    const double t = q.t;
+    double f = q.c[4].y, sv = q.c[9].y;
+    f = fma_(f, t, q.c[4].x);  sv = fma_(sv, t, q.c[9].x);
+    f = fma_(f, t, q.c[3].y);  sv = fma_(sv, t, q.c[8].y);
+    f = fma_(f, t, q.c[3].x);  sv = fma_(sv, t, q.c[8].x);
+    f = fma_(f, t, q.c[2].y);  sv = fma_(sv, t, q.c[7].y);
+    f = fma_(f, t, q.c[2].x);  sv = fma_(sv, t, q.c[7].x);
+    f = fma_(f, t, q.c[1].y);  sv = fma_(sv, t, q.c[6].y);
+    f = fma_(f, t, q.c[1].x);  sv = fma_(sv, t, q.c[6].x);
+    f = fma_(f, t, q.c[0].y);  sv = fma_(sv, t, q.c[5].y);
+    f = fma_(f, t, q.c[0].x);  sv = fma_(sv, t, q.c[5].x);
+    lse = ((eta > 0.0) ? eta : 0.0) + f;
+    sg = (eta >= 0.0) ? 1.0 - sv : sv;
+}
+
+RMH_DEV void logistic_terms(double eta, const double *tab, double &lse, double &sg)
+{
+    LogiGather q;
+    logistic_gather(eta, tab, q);
+    logistic_finish(eta, q, lse, sg);
 }
 
 // ---- one standard normal per 64-bit word: table-driven inverse CDF (rmh-rng v2)

@@ -112,7 +112,12 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
     RMH_NT_DISPATCH(NT, {
         using M = LogRegModel<kNT>;
         const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
-        return launch(k_run_hmc<M, 4>, c.nblocks, 4, lds, st, m, p, c, r);
+#ifdef RMH_LR_NW8
+        constexpr int NW = (kNT >= 7) ? 8 : 4;
+#else
+        constexpr int NW = 4;
+#endif
+        return launch(k_run_hmc<M, NW>, c.nblocks, NW, lds, st, m, p, c, r);
     })
 }
 

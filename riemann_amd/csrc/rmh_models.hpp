@@ -106,11 +106,15 @@ struct GaussModel {
 // rows, 0 for padding rows), padded to a whole KiB, so that a stage is moved by
 // 1-KiB global_load_lds pieces (HBM/L2 -> LDS with no VGPR staging).
 // Element (row i, column k) of a row tile sits in tile s = k>>2 at 8-byte slot
-//     (k&3)*16 + (i ^ F),   F = ((s&3)<<2) | (((k&3)>>1)<<1)
-// The XOR makes BOTH operand fetches conflict-free ds_read_b64's of the same
-// image:  eta = X beta   reads A[m=row][k=col]   (lane: row cl, col 4s+g)
+//     (k&3)*16 + (i ^ F),   F = ((s&3)<<2) | (k&3)
+// The XOR makes BOTH operand fetches conflict-free reads of the same image:
+//         eta = X beta   reads A[m=row][k=col]   (lane: row cl, col 4s+g)
 //         g  += X^T r    reads A[m=col][k=row]   (lane: col 16i+cl, row 4r+g)
-// so X is stored, moved and staged exactly once.
+// under either LDS banking: ds_read_b64 (32-lane groups, 64 banks) and the
+// ds_read2(st64)_b64 pairs the compiler merges them into (16-lane groups, 32
+// banks) -- a first version with F = ((s&3)<<2)|((k&3)>>1<<1) was 2-way
+// conflicted under the latter (SQ_LDS_BANK_CONFLICT = 30 % of LDS cycles).
+// So X is stored, moved and staged exactly once.
 constexpr int kLogRegCH = 2;
 constexpr int kChunkDoubles(int NT) { return kLogRegCH * 256 * NT + 128; }
 
@@ -127,8 +131,12 @@ struct LogRegModel {
     static constexpr int CHD = kChunkDoubles(NT);  // doubles per stage
     static constexpr int NP = CHD / 128;           // 1-KiB DMA pieces per stage
 
-    static constexpr __host__ __device__ size_t lds_doubles(bool) { return (size_t)2 * CHD; }
-    static RMH_DEV void setup(double *, const Args &, bool) {}
+    static constexpr __host__ __device__ size_t lds_doubles(bool) { return (size_t)2 * CHD + kLogiDoubles; }
+    // LDS: [stage 0][stage 1][link-function table]
+    static RMH_DEV void setup(double *lds, const Args &m, bool)
+    {
+        for (int i = threadIdx.x; i < kLogiDoubles; i += blockDim.x) lds[2 * CHD + i] = m.logi[i];
+    }
 
     // asynchronous copy of stage `chunk` into `dst` (LDS): wave w moves pieces
     // w, w+NW, ...; completion = s_waitcnt vmcnt(0), which __syncthreads() issues
@@ -141,32 +149,59 @@ struct LogRegModel {
                                              (lds_void_t *)(dst + j * 128), 16, 0, 0);
     }
 
-    // one row tile: eta (4*NT MFMAs), link function, gradient (4*NT MFMAs)
-    template <bool GRAD>
-    static RMH_DEV void row_tile(const double *img, const double *yw, const int (&eoff)[4],
-                                 const int (&goff)[4], int g, const double (&th)[S], double &ll,
-                                 double4_t (&G)[NT])
+    static RMH_DEV double4_t eta_tile(const double *img, const int (&eoff)[4], int ks,
+                                      const double (&th)[S])
     {
         double4_t eta = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < S; ++s) eta = mfma(img[s * 64 + eoff[s & 3]], th[s], eta);
-        double res[4];
+        for (int s = 0; s < S; ++s) // k-steps beyond ceil(d/4) multiply zero columns: skipped
+            if (s < S - 4 || s < ks) eta = mfma(img[s * 64 + eoff[s & 3]], th[s], eta);
+        return eta;
+    }
+
+    static RMH_DEV void grad_tile(const double *img, const int (&goff)[4], const double (&res)[4],
+                                  double4_t (&G)[NT])
+    {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const double e = (r == 0) ? eta.x : (r == 1) ? eta.y : (r == 2) ? eta.z : eta.w;
-            const double yv = yw[4 * r + g], wv = yw[16 + 4 * r + g];
-            double lse, sg;
-            logistic_terms(e, lse, sg);
-            ll += wv * (yv * e - lse);
-            res[r] = wv * (yv - sg);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) G[i] = mfma(img[i * 256 + goff[r]], res[r], G[i]);
         }
-        if (GRAD) {
+    }
+
+    static RMH_DEV double comp(const double4_t &v, int r)
+    {
+        return (r == 0) ? v.x : (r == 1) ? v.y : (r == 2) ? v.z : v.w;
+    }
+
+    // One stage = CH row tiles, one after the other: eta (4*NT MFMAs), link function
+    // of the lane's 4 values, gradient (4*NT MFMAs).  Measured alternatives that were
+    // slower on MI355X: all eta / all link / all gradient phases (0.48 vs 0.51 of the
+    // roof; 8 values in flight spill into AGPR traffic) and a hand pipeline that
+    // parks the table gathers across the next MFMA block (0.48; 160 more live VGPRs).
+    template <bool GRAD>
+    static RMH_DEV void stage_compute(const double *cur, const double *ltab, const int (&eoff)[4],
+                                      const int (&goff)[4], int g, int ks, const double (&th)[S],
+                                      double &ll, double4_t (&G)[NT])
+    {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const double *img = cur + k * XT, *yw = cur + CH * XT + k * 32;
+            const double4_t eta = eta_tile(img, eoff, ks, th);
+            double res[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int i = 0; i < NT; ++i)
-                    G[i] = mfma(img[i * 256 + goff[r]], res[r], G[i]);
+                const double e = comp(eta, r), yv = yw[4 * r + g], wv = yw[16 + 4 * r + g];
+                double lse, sg;
+#ifdef RMH_LOGI_CLOSED
+                logistic_terms_closed(e, lse, sg);
+#else
+                logistic_terms(e, ltab, lse, sg);
+#endif
+                ll += wv * (yv * e - lse);
+                res[r] = wv * (yv - sg);
             }
+            if (GRAD) grad_tile(img, goff, res, G);
         }
     }
 
@@ -180,9 +215,8 @@ struct LogRegModel {
         int eoff[4], goff[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            eoff[k] = g * 16 + (cl ^ ((k << 2) | ((g >> 1) << 1)));
-            const int Fl = ((cl >> 2) << 2) | (((cl & 3) >> 1) << 1);
-            goff[k] = (cl >> 2) * 64 + (cl & 3) * 16 + ((4 * k + g) ^ Fl);
+            eoff[k] = g * 16 + (cl ^ ((k << 2) | g));
+            goff[k] = (cl >> 2) * 64 + (cl & 3) * 16 + ((4 * k + g) ^ cl);
         }
         double4_t G[NT];
 #pragma unroll
@@ -194,9 +228,7 @@ struct LogRegModel {
         for (int64_t c = 0; c < m.nchunks; ++c) {
             const double *cur = lds + (c & 1) * CHD;
             if (c + 1 < m.nchunks) stage(m, c + 1, lds + ((c + 1) & 1) * CHD);
-#pragma unroll
-            for (int k = 0; k < CH; ++k)
-                row_tile<GRAD>(cur + k * XT, cur + CH * XT + k * 32, eoff, goff, g, th, ll, G);
+            stage_compute<GRAD>(cur, lds + 2 * CHD, eoff, goff, g, m.ks, th, ll, G);
             __syncthreads();
         }
         ll = sum4(ll);

@@ -46,6 +46,7 @@ def workload(name, chains):
                     theta0=th0, d=d, iters=1000, flops=2 * d * (d + 1) + 4 * d, bytes=8 * (d + 1),
                     bound="mfma", label="cfg2: 100-d correlated Gaussian, random-walk MH",
                     omodel=lambda o: o.Gaussian(np.zeros(d), Ct), oprop=lambda o: o.RandomWalk(Cp),
+                    twin=lambda t: (t.TwinGaussian(np.zeros(d), Ct), t.TwinRandomWalk(Cp), 20000),
                     cpu_sample=(65536, 200))
     if name in ("logreg_mala", "logreg_hmc"):   # configs[2] / configs[3]
         n, d = 10000, 100
@@ -59,6 +60,8 @@ def workload(name, chains):
                     label=("cfg3: logistic regression 10000x100, MALA" if L == 1 else
                            "cfg4: logistic regression 10000x100, HMC L=10"),
                     omodel=lambda o: o.LogReg(X, y, 100.0), oprop=lambda o: o.HMC(eps, L, d),
+                    twin=lambda t: ((lambda tm: (tm, t.TwinHMC(eps, L, tm.grad), 300 if L == 1 else 40))
+                                    (t.TwinLogReg(X, y, 100.0))),
                     cpu_sample=(4096, 4) if L == 1 else (2048, 2))
     if name == "changepoint_rw":                # configs[4]
         x, y, truth, cdiag = W.changepoint_data()
@@ -104,9 +107,20 @@ def cpu_baseline(w, seed):
     t0 = time.perf_counter()
     orc.run(m, p, th, lp, st, T, history=False, nthreads=threads)
     dt = time.perf_counter() - t0
-    return {"value": N * T / dt, "unit": "chain-iterations/s", "cores": threads, "kind": "port",
-            "sample": "%d chains x %d iterations of the same workload, oracle/rmh_oracle.c "
-                      "(OpenMP over chains), %.1f s" % (N, T, dt)}
+    out = {"value": N * T / dt, "unit": "chain-iterations/s", "cores": threads, "kind": "port",
+           "sample": "%d chains x %d iterations of the same workload, oracle/rmh_oracle.c "
+                     "(OpenMP over chains), %.1f s" % (N, T, dt)}
+    tw = w.get("twin")
+    if tw is not None:   # the reference-equivalent rate: numpy twin of the reference, 1 chain, 1 core
+        from oracle import py_twin
+        tm, tp, Tt = tw(py_twin)
+        xi, u = orc.rng_stream(orc.rng_seed(seed, 1), w["d"], Tt)
+        t0 = time.perf_counter()
+        py_twin.run_chain(tm, tp, w["theta0"][0], xi[:, 0], u[:, 0])
+        out["python_single_chain"] = {"value": Tt / (time.perf_counter() - t0), "cores": 1,
+                                      "sample": "oracle/py_twin.py (numpy twin of the reference's "
+                                                "Sampler/Proposal/Model), 1 chain x %d iterations" % Tt}
+    return out
 
 
 def tau_estimate(w, seed):

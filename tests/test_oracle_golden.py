@@ -200,3 +200,29 @@ def test_normals_are_standard_normal():
     c = np.corrcoef(xi.reshape(-1, 100), rowvar=False)
     assert np.abs(c - np.eye(100)).max() < 0.06
     assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.01
+
+
+def test_python_twin_matches_reference_fixtures():
+    """oracle/py_twin.py (the single-chain numpy twin timed by bench.py as the
+    'reference-equivalent' CPU rate) against the vectors recorded from the reference."""
+    from oracle import py_twin as tw
+    z = load("g2_gauss100d_rw")
+    Ct = corr100()
+    m, p = tw.TwinGaussian(z["mu"], Ct), tw.TwinRandomWalk(float(z["prop_factor"]) * Ct)
+    for c in (0, 5):
+        th, lp, acc = tw.run_chain(m, p, z["theta0"][c], z["xi"][:, c], z["u"][:, c])
+        np.testing.assert_array_equal(acc, z["accept"][:, c])
+        np.testing.assert_allclose(th, z["thetas"][:, c], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(lp, z["logpost"][:, c], rtol=1e-12)
+    z = load("g3_gauss100d_hmc10")
+    m = tw.TwinGaussian(np.zeros(100), Ct)
+    p = tw.TwinHMC(float(z["eps"]), int(z["nsteps"]), m.grad)
+    th, lp, acc = tw.run_chain(m, p, z["theta0"][1], z["xi"][:, 1], z["u"][:, 1])
+    np.testing.assert_array_equal(acc, z["accept"][:, 1])
+    np.testing.assert_allclose(lp, z["logpost"][:, 1], rtol=1e-10)
+    z = load("g4_logreg256x16_mala")
+    m = tw.TwinLogReg(z["X"], z["y"], float(z["tau2"]))
+    p = tw.TwinHMC(float(z["eps"]), 1, m.grad)
+    th, lp, acc = tw.run_chain(m, p, z["theta0"][2], z["xi"][:, 2], z["u"][:, 2])
+    np.testing.assert_array_equal(acc, z["accept"][:, 2])
+    np.testing.assert_allclose(lp, z["logpost"][:, 2], rtol=1e-10)

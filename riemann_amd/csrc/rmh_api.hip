@@ -397,6 +397,7 @@ int rmh_model_gaussian_create(const double *mu, const double *L, int d, rmh_mode
     m->ga.mu_pad = m->d_mu;
     m->ga.dlog2pi = d * std::log(2 * M_PI);   // gaussian.py:52
     m->ga.logdetC = 2 * slog;                 // gaussian.py:43
+    m->ga.ks = (d + 3) / 4;
     *out = m;
     return RMH_OK;
 }

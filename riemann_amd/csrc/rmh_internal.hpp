@@ -16,6 +16,7 @@ struct GaussArgs {
     const double *mu_pad;  // 16*NT doubles, zero padded
     double dlog2pi;        // d*log(2 pi)
     double logdetC;
+    int ks;                // ceil(d/4): k-steps that carry data
 };
 
 struct LogRegArgs {

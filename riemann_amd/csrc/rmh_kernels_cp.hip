@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs
             acc[i].z = pick<D>(th, 16 * i + 8, g);
             acc[i].w = pick<D>(th, 16 * i + 12, g);
         }
-        T::mul_lower(Limg + lane, xi, acc);
+        T::mul_lower(Limg + lane, xi, acc, ch.ks);
         double loc[S], thp[D];
         T::unpack(acc, loc);
 #pragma unroll

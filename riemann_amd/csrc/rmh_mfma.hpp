@@ -62,24 +62,32 @@ struct Tile {
     static constexpr int up(int i, int s) { return i * S - 2 * i * (i - 1) + (s - 4 * i); }
 
     // acc[i] += sum_{s <= 4i+3} A_lo(i,s) * B[s]     (A = lower-triangular image)
-    static RMH_DEV void mul_lower(const double *img_lane, const double (&B)[S], double4_t (&acc)[NT])
+    // k-steps s >= ks = ceil(d/4) carry B[s] = 0 (padding coordinates) and are
+    // skipped: only the last four can be, a wave-uniform test each.
+    static RMH_DEV void mul_lower(const double *img_lane, const double (&B)[S], double4_t (&acc)[NT],
+                                  int ks)
     {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
+            if (s < S - 4 || s < ks) {
 #pragma unroll
-            for (int i = s / 4; i < NT; ++i)
-                acc[i] = mfma(img_lane[lo(i, s) * 64], B[s], acc[i]);
+                for (int i = s / 4; i < NT; ++i)
+                    acc[i] = mfma(img_lane[lo(i, s) * 64], B[s], acc[i]);
+            }
         }
     }
 
     // acc[i] += sum_{s >= 4i} A_up(i,s) * B[s]       (A = upper-triangular image)
-    static RMH_DEV void mul_upper(const double *img_lane, const double (&B)[S], double4_t (&acc)[NT])
+    static RMH_DEV void mul_upper(const double *img_lane, const double (&B)[S], double4_t (&acc)[NT],
+                                  int ks)
     {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
+            if (s < S - 4 || s < ks) {
 #pragma unroll
-            for (int i = 0; i <= s / 4; ++i)
-                acc[i] = mfma(img_lane[up(i, s) * 64], B[s], acc[i]);
+                for (int i = 0; i <= s / 4; ++i)
+                    acc[i] = mfma(img_lane[up(i, s) * 64], B[s], acc[i]);
+            }
         }
     }
 

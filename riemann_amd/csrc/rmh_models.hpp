@@ -56,7 +56,7 @@ struct GaussModel {
             for (int s = 0; s < S; ++s) y[s] = th[s] - mu[4 * s + g];
 #pragma unroll
             for (int i = 0; i < NT; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
-            T::mul_lower(W, y, acc);
+            T::mul_lower(W, y, acc, m.ks);
 #pragma unroll
             for (int i = 0; i < NT; ++i)
                 uu += acc[i].x * acc[i].x + acc[i].y * acc[i].y + acc[i].z * acc[i].z +
@@ -71,9 +71,11 @@ struct GaussModel {
 #pragma unroll
                 for (int s = 0; s < 4 * (i0 + 2); ++s) {
                     if (s >= S) break;
-                    const double y = th[s] - mu[4 * s + g];
-                    if (s < 4 * (i0 + 1)) a0 = mfma(W[T::lo(i0, s) * 64], y, a0);
-                    if (i0 + 1 < NT) a1 = mfma(W[T::lo(i0 + 1 < NT ? i0 + 1 : i0, s) * 64], y, a1);
+                    if (s < S - 4 || s < m.ks) { // zero padding k-steps skipped
+                        const double y = th[s] - mu[4 * s + g];
+                        if (s < 4 * (i0 + 1)) a0 = mfma(W[T::lo(i0, s) * 64], y, a0);
+                        if (i0 + 1 < NT) a1 = mfma(W[T::lo(i0 + 1 < NT ? i0 + 1 : i0, s) * 64], y, a1);
+                    }
                 }
                 uu += a0.x * a0.x + a0.y * a0.y + a0.z * a0.z + a0.w * a0.w;
                 if (i0 + 1 < NT) uu += a1.x * a1.x + a1.y * a1.y + a1.z * a1.z + a1.w * a1.w;
@@ -90,7 +92,7 @@ struct GaussModel {
             double4_t v[NT];
 #pragma unroll
             for (int i = 0; i < NT; ++i) v[i] = double4_t{0.0, 0.0, 0.0, 0.0};
-            T::mul_upper(lds + kImg + lane, u, v);
+            T::mul_upper(lds + kImg + lane, u, v, m.ks);
             T::unpack(v, grad);
 #pragma unroll
             for (int s = 0; s < S; ++s) grad[s] = -grad[s];

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
         // theta' = theta + scale * L xi        (randomwalk.py:26; logqratio = 0.0)
         double4_t acc[NT];
         T::pack(th, acc);
-        T::mul_lower(Limg + lane, xi, acc);
+        T::mul_lower(Limg + lane, xi, acc, ch.ks);
         double thp[S], lpp, dummy[S], parts[2];
         T::unpack(acc, thp);
         M::template eval<false>(mlds, m, false, lane, thp, lpp, dummy, parts);
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(64 * NW) k_propose_rw(RwArgs pr, ChainArgs ch,
     T::normals(rng, ch.M, ch.d, g, tab, xi);
     double4_t acc[NT];
     T::pack(th, acc);
-    T::mul_lower(lds + lane, xi, acc);
+    T::mul_lower(lds + lane, xi, acc, ch.ks);
     T::unpack(acc, th);
     T::store_state(theta_p, ch.ld, c, g, th);
     xo_store(ch.rng, ch.nslots, slot, rng);

@@ -157,6 +157,7 @@ def main():
     if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
         import torch
         import torch.distributed as dist
+        local = local % max(torch.cuda.device_count(), 1)   # ranks that see one device each
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
@@ -258,9 +259,9 @@ def main():
     }
     if pooled:
         out["pool"] = pooled
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed at N=1 only
         out["cpu_baseline"] = cpu_baseline(w, a.seed)
-    if not a.no_ess:
+    if not a.no_ess and world == 1:
         try:
             tau, acc = tau_estimate(w, a.seed)
             out["ess"] = {"tau_int_max": tau, "accept_rate": acc, "ess_per_sec": value / tau,

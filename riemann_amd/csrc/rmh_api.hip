@@ -221,7 +221,7 @@ int ensure_grad(rmh_state *s)
         RMH_HIP(hipMemsetAsync(s->grad, 0, (size_t)s->dp * s->ld * sizeof(double), g_stream));
     }
     if (!s->mom) {
-        int rc = dev_alloc(&s->mom, (size_t)s->dp * (s->ld + 64));
+        int rc = dev_alloc(&s->mom, (size_t)s->dp * (s->ld + 128));
         if (rc) return rc;
     }
     ChainArgs c = chain_args(s);

@@ -44,7 +44,7 @@ struct ChainArgs {
     double *theta;      // (dp, ld), rows >= d are zero
     double *logpost;    // (ld)
     double *grad;       // (dp, ld) cached gradient of the log posterior (HMC), or null
-    double *mom;        // (dp, ld + 64) momentum parking space (HMC), or null
+    double *mom;        // (dp, ld + 128) momentum parking space (HMC), or null
     uint64_t *rng;      // 4 words x nslots
     int64_t ld;         // padded chain count (multiple of 16)
     int64_t nslots;     // 4*ld

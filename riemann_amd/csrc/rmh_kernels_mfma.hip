@@ -112,11 +112,11 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
     RMH_NT_DISPATCH(NT, {
         using M = LogRegModel<kNT>;
         const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
-#ifdef RMH_LR_NW8
+        // d > 64: eight waves per workgroup (two per SIMD, <= 256 registers each).  The
+        // second wave cannot overlap VALU with MFMA on this chip, but it fills the
+        // s_waitcnt / barrier gaps of the stage loop: 0.52 -> 0.61 of the FP64 roof,
+        // although the 256-register cap costs ~300 spilled registers outside the loop.
         constexpr int NW = (kNT >= 7) ? 8 : 4;
-#else
-        constexpr int NW = 4;
-#endif
         return launch(k_run_hmc<M, NW>, c.nblocks, NW, lds, st, m, p, c, r);
     })
 }

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
     const int64_t c = blk * 16 + cl;
     const int64_t slot = blk * 64 + lane;
 
-    // momentum parking column: ch.mom is (dp, ld + 64); the idle waves of the
+    // momentum parking column: ch.mom is (dp, ld + 128); the idle waves of the
     // last workgroup (which shadow its last block) get columns of their own
     const int64_t cm = active ? c : ch.ld + wave * 16 + cl;
     double lp = ch.logpost[c];
@@ -152,10 +152,10 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
         for (int step = 1; step <= pr.nsteps; ++step) {
             // the momentum is dead during the evaluation: park it in global memory
             // (L2) so that the evaluation has the register file to itself
-            T::store_state(ch.mom, ch.ld + 64, cm, g, p);
+            T::store_state(ch.mom, ch.ld + 128, cm, g, p);
             asm volatile("" ::: "memory");
             M::template eval<true>(lds, m, true, lane, q, lpp, gr, parts);
-            T::load_state(ch.mom, ch.ld + 64, cm, g, p);
+            T::load_state(ch.mom, ch.ld + 128, cm, g, p);
             const bool last = step == pr.nsteps;
             const double ek = last ? heps : eps; // :35 / :40
 #pragma unroll

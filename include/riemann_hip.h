@@ -22,7 +22,7 @@
  *    Model.log_posterior (models/model.py:49-52: nan or +-inf -> -inf) and the
  *    accept rule of Sampler.sample (samplers/sampler.py:83-84).
  *  - one device per process (rmh_init); handles are not thread-safe.
- *  - random numbers: the "rmh-rng v1" stream, keyed by
+ *  - random numbers: the "rmh-rng v2" stream, keyed by
  *    (seed, GLOBAL chain id); it replaces the process-global np.random used at
  *    proposals/randomwalk.py:25, proposals/hamiltonian.py:79, samplers/sampler.py:84.
  */
@@ -87,6 +87,12 @@ int rmh_proposal_rw_create(const double *L, int d, double scale, rmh_proposal_t 
 int rmh_proposal_hmc_create(double eps, int nsteps, int d, rmh_proposal_t *out);
 int rmh_proposal_set_scale(rmh_proposal_t p, double scale); /* .scale, randomwalk.py:18 */
 int rmh_proposal_set_eps(rmh_proposal_t p, double eps);     /* .eps, hamiltonian.py:69 */
+/* AdaptScaleProposal mix-in, proposals/adaptive.py:11-35: AdaptScaleRandomWalk
+ * (randomwalk.py:29-38, target 0.25) and AdaptScaleHMC (hamiltonian.py:94-104,
+ * target 0.75, eps = scale * eps0).  target > 0 switches the proposal to its
+ * adaptive variant; the per-chain state [Nsamples, Naccepts, scale] lives with the
+ * chains (rmh_state_get_adapt / rmh_state_set_adapt, (N,3) float64). */
+int rmh_proposal_set_adapt(rmh_proposal_t p, double target_accept_rate);
 int rmh_proposal_free(rmh_proposal_t p);
 
 /* Proposal.propose (proposal.py:10-17) for N states: theta (N,d) ->
@@ -104,6 +110,8 @@ int rmh_state_set_theta(rmh_state_t s, const double *theta);
 int rmh_state_get(rmh_state_t s, double *theta, double *logpost); /* current_state(), :56-60 */
 int rmh_state_get_rng(rmh_state_t s, uint64_t *rng);   /* (N,16) */
 int rmh_state_set_rng(rmh_state_t s, const uint64_t *rng);
+int rmh_state_get_adapt(rmh_state_t s, double *adapt);       /* (N,3) */
+int rmh_state_set_adapt(rmh_state_t s, const double *adapt);
 int rmh_state_device_ptrs(rmh_state_t s, void **theta_dn, void **logpost,
                           int64_t *ld);                 /* theta is (d, ld) on device */
 int rmh_state_free(rmh_state_t s);

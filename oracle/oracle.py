@@ -64,6 +64,9 @@ def lib():
     L.orc_proposal_hmc.argtypes = [dbl, i32, i32]
     L.orc_proposal_free.argtypes = [vp]
     L.orc_propose.argtypes = [vp, vp, _f64p, i64, _u64p, _f64p, _f64p]
+    L.orc_proposal_set_adapt.argtypes = [vp, dbl]
+    L.orc_run_adapt.restype = i32
+    L.orc_run_adapt.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, vp, vp, vp, i32, vp]
     L.orc_run.restype = i32
     L.orc_run.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, vp, vp, vp, i32]
     L.orc_max_threads.restype = i32
@@ -203,7 +206,20 @@ class HMC(_Proposal):
 
 
 # ----------------------------------------------------------------- sampler --
-def run(model, proposal, theta, logpost, rng_state, T, history=True, nthreads=0):
+def set_adapt(proposal, target):
+    """Turn a RandomWalk/HMC into its AdaptScale* variant (proposals/adaptive.py:11-35)."""
+    lib().orc_proposal_set_adapt(proposal._h, float(target))
+    return proposal
+
+
+def new_adapt_state(N):
+    """(N,3) [Nsamples, Naccepts, scale] as AdaptScaleProposal.__init__ (adaptive.py:18-23)."""
+    a = np.zeros((N, 3))
+    a[:, 2] = 1.0
+    return a
+
+
+def run(model, proposal, theta, logpost, rng_state, T, history=True, nthreads=0, adapt=None):
     """Sampler.run over N chains (/root/reference/riemann/samplers/sampler.py:44-90).
 
     ``theta`` (N,d), ``logpost`` (N,), ``rng_state`` (N,16) are advanced in
@@ -215,10 +231,11 @@ def run(model, proposal, theta, logpost, rng_state, T, history=True, nthreads=0)
     ht = np.empty((T + 1, N, d)) if history else None
     hl = np.empty((T + 1, N)) if history else None
     acc = np.empty((T, N), dtype=np.uint8)
-    rc = lib().orc_run(model._h, proposal._h, N, theta, logpost, rng_state, T,
-                       ht.ctypes.data if history else None,
-                       hl.ctypes.data if history else None,
-                       acc.ctypes.data, nthreads)
+    rc = lib().orc_run_adapt(model._h, proposal._h, N, theta, logpost, rng_state, T,
+                             ht.ctypes.data if history else None,
+                             hl.ctypes.data if history else None,
+                             acc.ctypes.data, nthreads,
+                             adapt.ctypes.data if adapt is not None else None)
     if rc != 0:
         raise ValueError("oracle: model and proposal dimensions differ")
     return ht, hl, acc

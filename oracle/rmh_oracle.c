@@ -456,6 +456,7 @@ typedef struct orc_proposal {
     double *L, scale; /* MetropolisRandomWalk: randomwalk.py:17-19 */
     double eps;       /* VanillaHMC: hamiltonian.py:60-74 (M=None only) */
     int nsteps;
+    double adapt_target; /* > 0: AdaptScaleProposal mix-in, proposals/adaptive.py:11-35 */
 } orc_proposal;
 
 orc_proposal *orc_proposal_rw(const double *L, int d, double scale)
@@ -472,6 +473,10 @@ orc_proposal *orc_proposal_hmc(double eps, int nsteps, int d)
     return p;
 }
 
+/* AdaptScaleRandomWalk (randomwalk.py:29-38, target 0.25) / AdaptScaleHMC
+ * (hamiltonian.py:94-104, target 0.75): enable the scale adaptation */
+void orc_proposal_set_adapt(orc_proposal *p, double target) { p->adapt_target = target; }
+
 void orc_proposal_free(orc_proposal *p)
 {
     if (!p) return;
@@ -483,19 +488,22 @@ void orc_proposal_free(orc_proposal *p)
  * RW : randomwalk.py:21-26.   HMC: hamiltonian.py:76-91 + leapfrog :13-52,
  * gradient callable = the model's grad of the log posterior. */
 static double orc_propose1(const orc_proposal *p, const orc_model *m, const double *th,
-                           const double *xi, double *thp, double *work)
+                           const double *xi, double *thp, double *work, double chain_scale)
 {
     const int d = p->d;
+    /* non-adaptive: the proposal's own .scale (randomwalk.py:18) / eps;
+     * adaptive: the chain's adapted scale, and eps = scale * eps0 (hamiltonian.py:101-102) */
+    const double scale = p->adapt_target > 0 ? chain_scale : p->scale;
     if (p->kind == ORC_RW) {
         for (int i = 0; i < d; i++) {
             double acc = 0; /* np.dot(L, xi) */
             for (int j = 0; j < d; j++) acc += p->L[i * d + j] * xi[j];
-            thp[i] = th[i] + p->scale * acc;
+            thp[i] = th[i] + scale * acc;
         }
         return 0.0;
     }
     double *mom = work, *g = work + d, *scr = work + 2 * d;
-    const double eps = p->eps;
+    const double eps = p->adapt_target > 0 ? chain_scale * p->eps : p->eps;
     orc_grad1(m, th, g, scr);
     for (int i = 0; i < d; i++) mom[i] = xi[i] + 0.5 * eps * g[i]; /* :27 */
     for (int i = 0; i < d; i++) thp[i] = th[i] + eps * mom[i];     /* :30 */
@@ -519,7 +527,7 @@ void orc_propose(const orc_proposal *p, const orc_model *m, const double *theta,
     double *xi = (double *)malloc(sizeof(double) * d * 4);
     for (int64_t c = 0; c < N; c++) {
         orc_rng_normals(rng + 16 * c, d, xi);
-        logq[c] = orc_propose1(p, m, theta + c * d, xi, theta_p + c * d, xi + d);
+        logq[c] = orc_propose1(p, m, theta + c * d, xi, theta_p + c * d, xi + d, 1.0);
     }
     free(xi);
 }
@@ -535,9 +543,23 @@ void orc_propose(const orc_proposal *p, const orc_model *m, const double *theta,
  * Accept rule, sampler.py:83-84: mhratio = min(0, D) with PYTHON min, i.e.
  * D if D < 0 else 0 (so NaN -> 0 -> accept); accept iff log(U) < mhratio.
  */
+/* adapt (N,3) or NULL: per chain [Nsamples, Naccepts, scale] of AdaptScaleProposal
+ * (adaptive.py:18-23), updated in place by adapt() after every step (sampler.py:88). */
+int orc_run_adapt(const orc_model *m, const orc_proposal *p, int64_t N, double *theta,
+                  double *logpost, u64 *rng, int T, double *hist_theta, double *hist_logpost,
+                  uint8_t *accept, int nthreads, double *adapt);
+
 int orc_run(const orc_model *m, const orc_proposal *p, int64_t N, double *theta,
             double *logpost, u64 *rng, int T, double *hist_theta, double *hist_logpost,
             uint8_t *accept, int nthreads)
+{
+    return orc_run_adapt(m, p, N, theta, logpost, rng, T, hist_theta, hist_logpost, accept,
+                         nthreads, NULL);
+}
+
+int orc_run_adapt(const orc_model *m, const orc_proposal *p, int64_t N, double *theta,
+                  double *logpost, u64 *rng, int T, double *hist_theta, double *hist_logpost,
+                  uint8_t *accept, int nthreads, double *adapt)
 {
     const int d = m->d;
     if (p->d != d) return -1;
@@ -556,7 +578,7 @@ int orc_run(const orc_model *m, const orc_proposal *p, int64_t N, double *theta,
             if (hist_logpost) hist_logpost[c] = logpost[c];
             for (int t = 0; t < T; t++) {
                 orc_rng_normals(st, d, xi);
-                const double logq = orc_propose1(p, m, th, xi, thp, w2);
+                const double logq = orc_propose1(p, m, th, xi, thp, w2, adapt ? adapt[3 * c + 2] : 1.0);
                 const double lp_prop = orc_log_post1(m, thp, w2);
                 const double delta = lp_prop - logpost[c] - logq;
                 const double mh = (delta < 0) ? delta : 0.0;
@@ -565,6 +587,15 @@ int orc_run(const orc_model *m, const orc_proposal *p, int64_t N, double *theta,
                 if (acc) {
                     memcpy(th, thp, sizeof(double) * d);
                     logpost[c] = lp_prop;
+                }
+                if (adapt && p->adapt_target > 0) { /* AdaptScaleProposal.adapt, adaptive.py:25-35 */
+                    double *a = adapt + 3 * c;
+                    /* the first call compares with last_theta = None: always "moved" */
+                    const int moved = (a[0] == 0.0) ? 1 : acc;
+                    a[0] += 1;
+                    a[1] += moved;
+                    const double rate = a[1] / a[0], ratio = exp(1.0 / a[0]);
+                    if (rate > p->adapt_target) a[2] *= ratio; else a[2] /= ratio;
                 }
                 if (accept) accept[(int64_t)t * N + c] = (uint8_t)acc;
                 if (hist_theta)

@@ -42,6 +42,7 @@ SIGNATURES = {
     "rmh_proposal_hmc_create": [_dbl, _int, _int, _pvp],
     "rmh_proposal_set_scale": [_vp, _dbl],
     "rmh_proposal_set_eps": [_vp, _dbl],
+    "rmh_proposal_set_adapt": [_vp, _dbl],
     "rmh_proposal_free": [_vp],
     "rmh_propose": [_vp, _vp, _f64, _i64, _u64, _f64, _f64],
     "rmh_state_create": [_vp, _i64, _u64s, _u64s, _pvp],
@@ -49,6 +50,8 @@ SIGNATURES = {
     "rmh_state_get": [_vp, _vp, _vp],
     "rmh_state_get_rng": [_vp, _u64],
     "rmh_state_set_rng": [_vp, _u64],
+    "rmh_state_get_adapt": [_vp, _f64],
+    "rmh_state_set_adapt": [_vp, _f64],
     "rmh_state_device_ptrs": [_vp, _pvp, _pvp, C.POINTER(_i64)],
     "rmh_state_free": [_vp],
     "rmh_history_create": [_vp, _i64, _i64, _pvp],

@@ -130,7 +130,7 @@ struct rmh_model {
 
 struct rmh_proposal {
     int kind = 0, d = 0, NT = 0;
-    double scale = 1.0, eps = 0.0;
+    double scale = 1.0, eps = 0.0, adapt_target = 0.0;
     int nsteps = 0;
     std::vector<double> L;     // host copy of the Cholesky factor
     double *d_Ltiles = nullptr;
@@ -142,6 +142,7 @@ struct rmh_state {
     int64_t N = 0, ld = 0;
     int d = 0, dp = 0, ks = 0, NT = 0;
     double *theta = nullptr, *grad = nullptr, *mom = nullptr, *logpost = nullptr;
+    double *adapt = nullptr; // 3 x ld: Nsamples, Naccepts, scale (AdaptScaleProposal)
     uint64_t *rng = nullptr;
     bool valid = false, grad_valid = false;
 };
@@ -177,7 +178,8 @@ ChainArgs chain_args(const rmh_state *s)
 int sync_proposal(rmh_proposal *p)
 {
     if (p->kind != kRW || !p->dirty) return RMH_OK;
-    std::vector<double> img = pack_lower(p->L.data(), p->d, p->NT, p->scale);
+    // adaptive variant: the chains carry their own scale, the image stays unscaled
+    std::vector<double> img = pack_lower(p->L.data(), p->d, p->NT, p->adapt_target > 0 ? 1.0 : p->scale);
     if (!p->d_Ltiles) {
         int rc = dev_alloc(&p->d_Ltiles, img.size());
         if (rc) return rc;
@@ -240,6 +242,7 @@ struct TmpState {
         (void)hipFree(s.theta);
         (void)hipFree(s.grad);
         (void)hipFree(s.mom);
+        (void)hipFree(s.adapt);
         (void)hipFree(s.logpost);
         (void)hipFree(s.rng);
         (void)hipFree(staging);
@@ -591,6 +594,15 @@ int rmh_proposal_set_eps(rmh_proposal_t p, double eps)
     return RMH_OK;
 }
 
+int rmh_proposal_set_adapt(rmh_proposal_t p, double target)
+{
+    if (!p) return fail(RMH_ERR_PARAM, "null proposal");
+    if (!(target >= 0.0 && target < 1.0)) return fail(RMH_ERR_PARAM, "adapt: target accept rate must be in [0, 1)");
+    if ((p->adapt_target > 0) != (target > 0)) p->dirty = true;
+    p->adapt_target = target;
+    return RMH_OK;
+}
+
 int rmh_proposal_free(rmh_proposal_t p)
 {
     if (!p) return RMH_OK;
@@ -750,6 +762,43 @@ int rmh_state_set_rng(rmh_state_t s, const uint64_t *rng)
     return RMH_OK;
 }
 
+static int ensure_adapt(rmh_state *s)
+{
+    if (s->adapt) return RMH_OK;
+    std::vector<double> init((size_t)3 * s->ld, 0.0);
+    for (int64_t c = 0; c < s->ld; ++c) init[2 * s->ld + c] = 1.0; // adaptive.py:23
+    return upload(&s->adapt, init.data(), init.size());
+}
+
+int rmh_state_get_adapt(rmh_state_t s, double *adapt)
+{
+    RMH_NEED_INIT();
+    if (!s || !adapt) return fail(RMH_ERR_PARAM, "bad argument");
+    int rc = ensure_adapt(s);
+    if (rc) return rc;
+    std::vector<double> h((size_t)3 * s->ld);
+    RMH_HIP(hipMemcpyAsync(h.data(), s->adapt, h.size() * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    RMH_HIP(hipStreamSynchronize(g_stream));
+    for (int64_t c = 0; c < s->N; ++c)
+        for (int k = 0; k < 3; ++k) adapt[c * 3 + k] = h[(size_t)k * s->ld + c];
+    return RMH_OK;
+}
+
+int rmh_state_set_adapt(rmh_state_t s, const double *adapt)
+{
+    RMH_NEED_INIT();
+    if (!s || !adapt) return fail(RMH_ERR_PARAM, "bad argument");
+    int rc = ensure_adapt(s);
+    if (rc) return rc;
+    std::vector<double> h((size_t)3 * s->ld, 0.0);
+    for (int64_t c = 0; c < s->ld; ++c) h[2 * s->ld + c] = 1.0;
+    for (int64_t c = 0; c < s->N; ++c)
+        for (int k = 0; k < 3; ++k) h[(size_t)k * s->ld + c] = adapt[c * 3 + k];
+    RMH_HIP(hipMemcpyAsync(s->adapt, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    RMH_HIP(hipStreamSynchronize(g_stream));
+    return RMH_OK;
+}
+
 int rmh_state_device_ptrs(rmh_state_t s, void **theta_dn, void **logpost, int64_t *ld)
 {
     if (!s) return fail(RMH_ERR_PARAM, "null state");
@@ -765,6 +814,7 @@ int rmh_state_free(rmh_state_t s)
     (void)hipFree(s->theta);
     (void)hipFree(s->grad);
     (void)hipFree(s->mom);
+    (void)hipFree(s->adapt);
     (void)hipFree(s->logpost);
     (void)hipFree(s->rng);
     delete s;
@@ -899,7 +949,15 @@ int rmh_run(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t n
     } else if ((rc = sync_proposal(p))) {
         return rc;
     }
+    const bool adapt = p->adapt_target > 0;
+    if (adapt) {
+        if (m->kind == kChangepoint)
+            return fail(RMH_ERR_PARAM, "run: scale adaptation is not built for the changepoint kernel yet");
+        if ((rc = ensure_adapt(s))) return rc;
+    }
     ChainArgs c = chain_args(s);
+    c.adapt = adapt ? s->adapt : nullptr;
+    c.adapt_target = p->adapt_target;
     RunArgs r{};
     r.T = T;
     r.nburn = nburn;
@@ -911,13 +969,13 @@ int rmh_run(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t n
     hipError_t e = hipSuccess;
     if (p->kind == kRW) {
         RwArgs ra{p->d_Ltiles, nullptr};
-        if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, g_stream);
+        if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
         else if (m->kind == kChangepoint) e = launch_cp_rw(m->k, m->ca, ra, c, r, g_stream);
         else return fail(RMH_ERR_PARAM, "run: random walk on the logistic model is not built yet");
     } else {
         HmcArgs ha{p->eps, p->nsteps};
-        if (m->kind == kGauss) e = launch_gauss_hmc(m->NT, m->ga, ha, c, r, g_stream);
-        else e = launch_logreg_hmc(m->NT, m->la, ha, c, r, g_stream);
+        if (m->kind == kGauss) e = launch_gauss_hmc(m->NT, m->ga, ha, c, r, adapt, g_stream);
+        else e = launch_logreg_hmc(m->NT, m->la, ha, c, r, adapt, g_stream);
     }
     RMH_HIP(e);
     RMH_HIP(hipEventRecord(g_ev1, g_stream));

@@ -54,6 +54,8 @@ struct ChainArgs {
     int ks;             // ceil(d/4): history entries hold 4*ks rows
     int M;              // normals (64-bit words) per sub-stream per iteration: ceil(d/4)
     const double *icdf; // inverse-normal-CDF table, 96-byte cell stride (rmh_device.hpp)
+    double *adapt;      // AdaptScaleProposal state, 3 rows of ld: Nsamples, Naccepts, scale; or null
+    double adapt_target;
 };
 
 struct RunArgs {
@@ -82,10 +84,11 @@ inline int nt_for_dim(int d) { return d <= 16 ? 1 : d <= 32 ? 2 : d <= 64 ? 4 : 
 hipError_t launch_gauss_eval(int NT, const GaussArgs &m, const ChainArgs &c, int want_grad,
                              double *lp_out, double *grad_out, double *lprior_out,
                              double *llik_out, hipStream_t st);
+// `adapt`: run the AdaptScale* variant (c.adapt / c.adapt_target set, tile image unscaled)
 hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
-                           const RunArgs &r, hipStream_t st);
+                           const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_gauss_hmc(int NT, const GaussArgs &m, const HmcArgs &p, const ChainArgs &c,
-                            const RunArgs &r, hipStream_t st);
+                            const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_propose_rw(int NT, const RwArgs &p, const ChainArgs &c, double *theta_p,
                              hipStream_t st);
 hipError_t launch_gauss_propose_hmc(int NT, const GaussArgs &m, const HmcArgs &p,
@@ -96,7 +99,7 @@ hipError_t launch_logreg_eval(int NT, const LogRegArgs &m, const ChainArgs &c, i
                               double *lp_out, double *grad_out, double *lprior_out,
                               double *llik_out, hipStream_t st);
 hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, const ChainArgs &c,
-                             const RunArgs &r, hipStream_t st);
+                             const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_logreg_propose_hmc(int NT, const LogRegArgs &m, const HmcArgs &p,
                                      const ChainArgs &c, double *theta_p, double *logq,
                                      hipStream_t st);

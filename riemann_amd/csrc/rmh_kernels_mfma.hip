@@ -47,7 +47,7 @@ hipError_t launch_gauss_eval(int NT, const GaussArgs &m, const ChainArgs &c, int
 }
 
 hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
-                           const RunArgs &r, hipStream_t st)
+                           const RunArgs &r, bool adapt, hipStream_t st)
 {
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
@@ -56,17 +56,19 @@ hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const Ch
         // eight waves give every SIMD a second wavefront to cover the s_waitcnt
         // stalls (LDS table reads of the normals, state/record traffic): +16 %
         constexpr int NW = (kNT >= 7) ? 8 : 4;
-        return launch(k_run_rw<M, NW>, c.nblocks, NW, lds, st, m, p, c, r);
+        if (adapt) return launch(k_run_rw<M, NW, true>, c.nblocks, NW, lds, st, m, p, c, r);
+        return launch(k_run_rw<M, NW, false>, c.nblocks, NW, lds, st, m, p, c, r);
     })
 }
 
 hipError_t launch_gauss_hmc(int NT, const GaussArgs &m, const HmcArgs &p, const ChainArgs &c,
-                            const RunArgs &r, hipStream_t st)
+                            const RunArgs &r, bool adapt, hipStream_t st)
 {
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
         const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
-        return launch(k_run_hmc<M, 4>, c.nblocks, 4, lds, st, m, p, c, r);
+        if (adapt) return launch(k_run_hmc<M, 4, true>, c.nblocks, 4, lds, st, m, p, c, r);
+        return launch(k_run_hmc<M, 4, false>, c.nblocks, 4, lds, st, m, p, c, r);
     })
 }
 
@@ -107,7 +109,7 @@ hipError_t launch_logreg_eval(int NT, const LogRegArgs &m, const ChainArgs &c, i
 }
 
 hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, const ChainArgs &c,
-                             const RunArgs &r, hipStream_t st)
+                             const RunArgs &r, bool adapt, hipStream_t st)
 {
     RMH_NT_DISPATCH(NT, {
         using M = LogRegModel<kNT>;
@@ -117,7 +119,8 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
         // s_waitcnt / barrier gaps of the stage loop: 0.52 -> 0.61 of the FP64 roof,
         // although the 256-register cap costs ~300 spilled registers outside the loop.
         constexpr int NW = (kNT >= 7) ? 8 : 4;
-        return launch(k_run_hmc<M, NW>, c.nblocks, NW, lds, st, m, p, c, r);
+        if (adapt) return launch(k_run_hmc<M, NW, true>, c.nblocks, NW, lds, st, m, p, c, r);
+        return launch(k_run_hmc<M, NW, false>, c.nblocks, NW, lds, st, m, p, c, r);
     })
 }
 

@@ -35,13 +35,41 @@ struct Keep {
     }
 };
 
+// AdaptScaleProposal (riemann/proposals/adaptive.py:11-35) per chain: the adapt()
+// hook of sampler.py:88 after every step.  State in ch.adapt: rows Nsamples,
+// Naccepts, scale.  The first call compares with last_theta = None and therefore
+// always counts as a move (adaptive.py:27 with :22).
+struct AdaptScale {
+    double n, acc, scale;
+    RMH_DEV void load(const ChainArgs &ch, int64_t c)
+    {
+        n = ch.adapt[c];
+        acc = ch.adapt[ch.ld + c];
+        scale = ch.adapt[2 * ch.ld + c];
+    }
+    RMH_DEV void store(const ChainArgs &ch, int64_t c) const
+    {
+        ch.adapt[c] = n;
+        ch.adapt[ch.ld + c] = acc;
+        ch.adapt[2 * ch.ld + c] = scale;
+    }
+    RMH_DEV void adapt(bool accepted, double target)
+    {
+        const double moved = (n == 0.0 || accepted) ? 1.0 : 0.0;
+        n += 1.0;
+        acc += moved;
+        const double ratio = exp(1.0 / n);
+        scale = (acc / n > target) ? scale * ratio : scale / ratio;
+    }
+};
+
 // ------------------------------------------------------------- random walk --
 // On MI355X v_mfma_f64 and the VALU do not overlap across wavefronts
 // (tools/microbench2.hip): a second resident wave cannot hide VALU work behind
 // MFMAs, it only covers s_waitcnt stalls.  The chain state, the candidate and the
 // normals all stay in registers (<= 256 at two waves per SIMD) and the only HBM
 // traffic of an iteration is the recorded sample.
-template <class M, int NW>
+template <class M, int NW, bool ADAPT>
 __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
@@ -69,6 +97,8 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
     Xo rng = xo_load(ch.rng, ch.nslots, slot);
     Keep keep(run);
     keep.record<NT>(run, ch, 0, c, g, active, th, lp);
+    AdaptScale ad{0.0, 0.0, 1.0};
+    if (ADAPT) ad.load(ch, c);
 
     for (int64_t t = 0; t < run.T; ++t) {
         // the tile images never change, so without this fence LICM hoists their
@@ -78,22 +108,33 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
         T::normals(rng, ch.M, ch.d, g, tab, xi);
         // theta' = theta + scale * L xi        (randomwalk.py:26; logqratio = 0.0)
         double4_t acc[NT];
-        T::pack(th, acc);
-        T::mul_lower(Limg + lane, xi, acc, ch.ks);
         double thp[S], lpp, dummy[S], parts[2];
-        T::unpack(acc, thp);
+        if (ADAPT) { // the chain's own adapted scale: theta + scale * (L xi), image unscaled
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+            T::mul_lower(Limg + lane, xi, acc, ch.ks);
+            T::unpack(acc, thp);
+#pragma unroll
+            for (int s = 0; s < S; ++s) thp[s] = th[s] + ad.scale * thp[s];
+        } else {
+            T::pack(th, acc);
+            T::mul_lower(Limg + lane, xi, acc, ch.ks);
+            T::unpack(acc, thp);
+        }
         M::template eval<false>(mlds, m, false, lane, thp, lpp, dummy, parts);
         const double u = T::accept_uniform(rng, g, cl);
         const bool acc_ok = mh_accept(lpp, lp, 0.0, u);
 #pragma unroll
         for (int s = 0; s < S; ++s) th[s] = acc_ok ? thp[s] : th[s];
         lp = acc_ok ? lpp : lp;
+        if (ADAPT) ad.adapt(acc_ok, ch.adapt_target);
         if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = acc_ok ? 1 : 0;
         keep.record<NT>(run, ch, t + 1, c, g, active, th, lp);
     }
     if (active) {
         T::store_state(ch.theta, ch.ld, c, g, th);
         if (g == 0) ch.logpost[c] = lp;
+        if (ADAPT && g == 0) ad.store(ch, c);
         xo_store(ch.rng, ch.nslots, slot, rng);
     }
 }
@@ -104,7 +145,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
 // reference's re-evaluation, hamiltonian.py:27), and the last gradient call of
 // the trajectory (:40) is fused with the log_posterior call of sampler.py:82.
 // Current state and cached gradient live in global memory between iterations.
-template <class M, int NW>
+template <class M, int NW, bool ADAPT>
 __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs pr, ChainArgs ch, RunArgs run)
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
@@ -128,8 +169,10 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
     const int64_t cm = active ? c : ch.ld + wave * 16 + cl;
     double lp = ch.logpost[c];
     Xo rng = xo_load(ch.rng, ch.nslots, slot);
-    const double eps = pr.eps, heps = 0.5 * pr.eps;
+    double eps = pr.eps, heps = 0.5 * pr.eps;
     Keep keep(run);
+    AdaptScale ad{0.0, 0.0, 1.0};
+    if (ADAPT) ad.load(ch, c);
 
     for (int64_t t = 0; t <= run.T; ++t) {
         asm volatile("" ::: "memory"); // no LICM of the LDS tile reads (see k_run_rw)
@@ -138,6 +181,10 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
         T::load_state(ch.theta, ch.ld, c, g, q);
         keep.record<NT>(run, ch, t, c, g, active, q, lp);
         if (t == run.T) break;
+        if (ADAPT) { // AdaptScaleHMC.propose: eps = scale * eps0 (hamiltonian.py:101-102)
+            eps = ad.scale * pr.eps;
+            heps = 0.5 * eps;
+        }
         double k0 = 0.0;
 #pragma unroll
         for (int s = 0; s < S; ++s) k0 += p[s] * p[s];
@@ -178,10 +225,12 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
             }
             lp = lpp;
         }
+        if (ADAPT) ad.adapt(acc_ok, ch.adapt_target);
         if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = acc_ok ? 1 : 0;
     }
     if (active) {
         if (g == 0) ch.logpost[c] = lp;
+        if (ADAPT && g == 0) ad.store(ch, c);
         xo_store(ch.rng, ch.nslots, slot, rng);
     }
 }

@@ -1,5 +1,7 @@
 from .proposal import Proposal, DeviceProposal
-from .randomwalk import MetropolisRandomWalk
-from .hamiltonian import VanillaHMC, MALA
+from .adaptive import AdaptScaleProposal
+from .randomwalk import MetropolisRandomWalk, AdaptScaleRandomWalk
+from .hamiltonian import VanillaHMC, MALA, AdaptScaleHMC
 
-__all__ = ["Proposal", "DeviceProposal", "MetropolisRandomWalk", "VanillaHMC", "MALA"]
+__all__ = ["Proposal", "DeviceProposal", "MetropolisRandomWalk", "VanillaHMC", "MALA",
+           "AdaptScaleProposal", "AdaptScaleRandomWalk", "AdaptScaleHMC"]

@@ -10,6 +10,7 @@ import ctypes as C
 
 from .. import _lib
 from ..models.model import DeviceModel
+from .adaptive import AdaptScaleProposal
 from .proposal import DeviceProposal
 
 
@@ -47,3 +48,16 @@ class MALA(VanillaHMC):
 
     def __init__(self, eps, gradlogpost):
         VanillaHMC.__init__(self, eps, 1, gradlogpost)
+
+
+class AdaptScaleHMC(AdaptScaleProposal, VanillaHMC):
+    """HMC whose step size is eps = scale * eps0 with the scale adapted towards an
+    accept rate of 0.75 (hamiltonian.py:94-104), per chain."""
+
+    def __init__(self, eps, Nsteps, gradlogpost, M=None):
+        VanillaHMC.__init__(self, eps, Nsteps, gradlogpost, M=M)
+        self._init_adapt(0.75)
+        self.eps0 = self.eps
+
+    def _sync(self):
+        _lib.call("rmh_proposal_set_eps", self._h, float(self.eps0))

@@ -4,6 +4,7 @@ import ctypes as C
 import numpy as np
 
 from .. import _lib
+from .adaptive import AdaptScaleProposal
 from .proposal import DeviceProposal
 
 
@@ -22,3 +23,15 @@ class MetropolisRandomWalk(DeviceProposal):
 
     def _sync(self):
         _lib.call("rmh_proposal_set_scale", self._h, float(self.scale))
+
+
+class AdaptScaleRandomWalk(AdaptScaleProposal, MetropolisRandomWalk):
+    """A Metropolis random walk that adapts only the overall scale, target accept
+    rate 0.25 (randomwalk.py:29-38).  ``.scale`` is adapted per chain by the kernel."""
+
+    def __init__(self, C_):
+        MetropolisRandomWalk.__init__(self, C_)
+        self._init_adapt(0.25)
+
+    def _sync(self):
+        pass  # the scale is the chains' state, not the proposal's

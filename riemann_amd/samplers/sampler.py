@@ -131,6 +131,8 @@ class Sampler(object):
         _lib.call("rmh_last_run_ms", C.byref(ms), None)
         self.last_run_ms = ms.value
         self._kept, self._iters = kept, T
+        if hasattr(self.proposal, "_pull_adapt"):   # AdaptScale*: publish the adapted scales
+            self.proposal._pull_adapt({"handle": self._state, "N": self.Nchains}, self._single)
         if record:
             self._host_thetas = self._host_logpost = self._host_accept = None
         else:

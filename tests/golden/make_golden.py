@@ -61,7 +61,7 @@ class Replay:
         return float(v)
 
 
-def run_reference(model, make_proposal, theta0, seed, T, runs=None):
+def run_reference(model, make_proposal, theta0, seed, T, runs=None, capture=None):
     """Run the reference Sampler for every chain on the injected stream.
 
     theta0 (N,d).  ``runs`` = list of (Nsamples, Nburn, Nthin) executed back to
@@ -93,8 +93,14 @@ def run_reference(model, make_proposal, theta0, seed, T, runs=None):
                     per_run[k]["accept"].append(
                         np.array([th[t + 1] is not th[t] for t in range(ns)], dtype=np.uint8))
             assert rp.tn == Ttot and rp.tu == Ttot
+            if capture is not None:
+                for key, val in capture(s.proposal).items():
+                    out.setdefault(key, []).append(val)
     finally:
         np.random.normal, np.random.uniform = real_normal, real_uniform
+    if capture is not None:
+        for key in [k for k in out if isinstance(out[k], list)]:
+            out[key] = np.array(out[key])
     for k, pr in enumerate(per_run):
         sfx = "" if len(runs) == 1 else "_run%d" % k
         out["thetas" + sfx] = np.stack(pr["thetas"], axis=1)    # (Tk, N, d)
@@ -332,6 +338,34 @@ def g7_errors():
     save("g7_errors", **{k: np.array(v) for k, v in msgs.items()})
 
 
+# ------------------------------------------- G8: scale adaptation --
+def g8_adapt_scale():
+    """AdaptScaleRandomWalk (proposals/randomwalk.py:29-38) and AdaptScaleHMC
+    (proposals/hamiltonian.py:94-104): the adapt() hook of sampler.py:88."""
+    from riemann.proposals.hamiltonian import AdaptScaleHMC
+    from riemann.proposals.randomwalk import AdaptScaleRandomWalk
+
+    def cap(p):
+        return dict(ad_n=p.Nsamples, ad_acc=p.Naccepts, ad_scale=p.scale, ad_rate=p.accept_rate)
+
+    m2 = rbench.benchmark_gauss2d_corr
+    r = run_reference(m2, lambda: AdaptScaleRandomWalk(np.eye(2)), np.ones((4, 2)), seed=80, T=200,
+                      capture=cap)
+    save("g8_adapt_rw_gauss2d", mu=np.zeros(2), C=0.1 * np.eye(2) + 0.9 * np.ones((2, 2)),
+         Cprop=np.eye(2), target=np.float64(0.25), **r)
+    Ct = corr100()
+    th0 = np.random.default_rng(8).standard_normal((4, 100)) @ np.linalg.cholesky(Ct).T
+    m = rbench.benchmark_gauss100d_corr
+    r = run_reference(m, lambda: AdaptScaleRandomWalk(0.05 * Ct), th0, seed=81, T=64, capture=cap)
+    r.pop("xi")
+    save("g8_adapt_rw_gauss100d", prop_factor=np.float64(0.05), target=np.float64(0.25), **r)
+    r = run_reference(m, lambda: AdaptScaleHMC(0.2, 5, m.grad_log_likelihood), th0, seed=82, T=40,
+                      capture=cap)
+    r.pop("xi")
+    save("g8_adapt_hmc_gauss100d", eps0=np.float64(0.2), nsteps=np.int64(5),
+         target=np.float64(0.75), **r)
+
+
 if __name__ == "__main__":
     g0_rng()
     g1_gauss2d_rw()
@@ -341,3 +375,4 @@ if __name__ == "__main__":
     args = g5_changepoint()
     g6_edges(*args)
     g7_errors()
+    g8_adapt_scale()

@@ -426,3 +426,54 @@ def test_full_size_sharding_and_resume_invariance(ra):
     np.testing.assert_array_equal(lp_t, lp_w)
     np.testing.assert_array_equal(two._chain_thetas, whole._chain_thetas[6::3])
     assert 0.15 < acc_w.mean() < 0.35
+
+
+# ----------------------------- scale adaptation on the device
+def _adapt_gpu_check(ra, z, model, prop, T):
+    s = ra.Sampler(model, prop, z["theta0"], seed=int(z["seed"]))
+    s.run(T)
+    check_run(z, s)
+    np.testing.assert_array_equal(prop.Nsamples, z["ad_n"])
+    np.testing.assert_array_equal(prop.Naccepts, z["ad_acc"])
+    np.testing.assert_allclose(prop.scale, z["ad_scale"], rtol=1e-12)
+    np.testing.assert_allclose(prop.accept_rate, z["ad_rate"], rtol=1e-15)
+    return s
+
+
+def test_g8_adapt_scale_random_walk(ra):
+    from riemann_amd.models import MultiGaussianDist, benchmarks
+    from riemann_amd.proposals import AdaptScaleRandomWalk
+    z = load("g8_adapt_rw_gauss2d")
+    s = _adapt_gpu_check(ra, z, MultiGaussianDist(z["mu"], z["C"]), AdaptScaleRandomWalk(z["Cprop"]), 200)
+    s.run(10)                                  # adaptation state persists across run() calls
+    assert np.all(s.proposal.Nsamples == 210)
+    z = load("g8_adapt_rw_gauss100d")
+    _adapt_gpu_check(ra, z, benchmarks.benchmark_gauss100d_corr,
+                     AdaptScaleRandomWalk(float(z["prop_factor"]) * corr100()), 64)
+
+
+def test_g8_adapt_scale_hmc(ra):
+    from riemann_amd.models import benchmarks
+    from riemann_amd.proposals import AdaptScaleHMC
+    z = load("g8_adapt_hmc_gauss100d")
+    m = benchmarks.benchmark_gauss100d_corr
+    _adapt_gpu_check(ra, z, m, AdaptScaleHMC(float(z["eps0"]), int(z["nsteps"]), m.grad_log_likelihood), 40)
+
+
+def test_adapt_scale_many_chains_vs_oracle(ra, orc):
+    from riemann_amd.models import LogisticRegression
+    from riemann_amd.proposals import AdaptScaleHMC
+    from riemann_amd.workloads import logreg_data
+    X, y = logreg_data(512, 24, seed=3)
+    th0 = 0.1 * np.random.default_rng(7).standard_normal((300, 24))
+    m = LogisticRegression(X, y, 100.0)
+    p = AdaptScaleHMC(0.3, 3, m)
+    s = ra.Sampler(m, p, th0, seed=21)
+    s.run(30)
+    om = orc.LogReg(X, y, 100.0)
+    th, ad = th0.copy(), orc.new_adapt_state(300)
+    ht, hl, acc = orc.run(om, orc.set_adapt(orc.HMC(0.3, 3, 24), 0.75), th, om.log_posterior(th),
+                          orc.rng_seed(21, 300), 30, adapt=ad)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(p.scale, ad[:, 2], rtol=1e-12)

@@ -226,3 +226,28 @@ def test_python_twin_matches_reference_fixtures():
     th, lp, acc = tw.run_chain(m, p, z["theta0"][2], z["xi"][:, 2], z["u"][:, 2])
     np.testing.assert_array_equal(acc, z["accept"][:, 2])
     np.testing.assert_allclose(lp, z["logpost"][:, 2], rtol=1e-10)
+
+
+def _adapt_check(z, model, prop, T):
+    th = np.ascontiguousarray(z["theta0"]).copy()
+    N = th.shape[0]
+    ad = orc.new_adapt_state(N)
+    ht, hl, acc = orc.run(model, orc.set_adapt(prop, float(z["target"])), th, model.log_posterior(th),
+                          orc.rng_seed(int(z["seed"]), N), T, adapt=ad)
+    check_run(z, ht, hl, acc)
+    np.testing.assert_array_equal(ad[:, 0], z["ad_n"])
+    np.testing.assert_array_equal(ad[:, 1], z["ad_acc"])
+    np.testing.assert_allclose(ad[:, 2], z["ad_scale"], rtol=1e-12)
+    np.testing.assert_allclose(ad[:, 1] / ad[:, 0], z["ad_rate"], rtol=1e-15)
+
+
+def test_g8_adaptive_scale_random_walk_and_hmc():
+    """AdaptScaleRandomWalk / AdaptScaleHMC (proposals/adaptive.py:11-35) incl. the
+    first-call quirk (last_theta is None => counted as a move)."""
+    z = load("g8_adapt_rw_gauss2d")
+    _adapt_check(z, orc.Gaussian(z["mu"], z["C"]), orc.RandomWalk(z["Cprop"]), 200)
+    z = load("g8_adapt_rw_gauss100d")
+    Ct = corr100()
+    _adapt_check(z, orc.Gaussian(np.zeros(100), Ct), orc.RandomWalk(float(z["prop_factor"]) * Ct), 64)
+    z = load("g8_adapt_hmc_gauss100d")
+    _adapt_check(z, orc.Gaussian(np.zeros(100), Ct), orc.HMC(float(z["eps0"]), int(z["nsteps"]), 100), 40)

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""The reference's examples/test_randomwalk.py on the MI355X back end: build a
+proposal, run the sampler, print the autocorrelation time and the accept rate.
+
+Differences from the reference script: 4096 chains instead of one (one fused
+kernel launch for all of them), the build's own tau estimator instead of emcee
+(not installed), no plots.  Usage:  python examples/randomwalk_mi355x.py
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from riemann_amd import Sampler                                         # noqa: E402
+from riemann_amd import diagnostics                                      # noqa: E402
+from riemann_amd.models.benchmarks import benchmark_gauss2d_corr         # noqa: E402
+from riemann_amd.proposals.hamiltonian import AdaptScaleHMC, VanillaHMC  # noqa: E402
+from riemann_amd.proposals.randomwalk import AdaptScaleRandomWalk, MetropolisRandomWalk  # noqa: E402
+
+
+def test_sampling_gauss2d(nchains=4096):
+    model = benchmark_gauss2d_corr
+    grad = model.grad_log_likelihood
+    for name, proposal in (("MetropolisRandomWalk", MetropolisRandomWalk(np.eye(2))),
+                           ("AdaptScaleRandomWalk", AdaptScaleRandomWalk(np.eye(2))),
+                           ("VanillaHMC(0.1, 5)", VanillaHMC(0.1, 5, grad)),
+                           ("AdaptScaleHMC(0.1, 5)", AdaptScaleHMC(0.1, 5, grad))):
+        sampler = Sampler(model, proposal, np.ones((nchains, 2)), seed=0)
+        sampler.run(10000, 1000, 1)
+        chain = sampler._chain_thetas                       # (9001, nchains, 2)
+        tau = diagnostics.integrated_time(chain[:, :64])
+        print("%-24s tau = %s  accept = %.3f  mean = %s  %.1f ms on the GPU"
+              % (name, np.round(tau, 1), sampler._chain_accept.mean(),
+                 np.round(chain.mean(axis=(0, 1)), 3), sampler.last_run_ms))
+
+
+if __name__ == "__main__":
+    test_sampling_gauss2d()

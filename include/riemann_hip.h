@@ -85,6 +85,9 @@ int rmh_proposal_rw_create(const double *L, int d, double scale, rmh_proposal_t 
 /* VanillaHMC(eps, Nsteps, gradlogpost, M=None), proposals/hamiltonian.py:60-91;
  * the gradient is the device Model's.  Nsteps = 1 is MALA. */
 int rmh_proposal_hmc_create(double eps, int nsteps, int d, rmh_proposal_t *out);
+/* VanillaHMC(..., M): mass matrix, hamiltonian.py:71-74.  chM = cholesky(M), lower,
+ * (d,d) row-major; NULL removes it.  (Fused run only; rmh_propose takes M = None.) */
+int rmh_proposal_hmc_set_mass(rmh_proposal_t p, const double *chM);
 int rmh_proposal_set_scale(rmh_proposal_t p, double scale); /* .scale, randomwalk.py:18 */
 int rmh_proposal_set_eps(rmh_proposal_t p, double eps);     /* .eps, hamiltonian.py:69 */
 /* AdaptScaleProposal mix-in, proposals/adaptive.py:11-35: AdaptScaleRandomWalk

@@ -65,6 +65,7 @@ def lib():
     L.orc_proposal_free.argtypes = [vp]
     L.orc_propose.argtypes = [vp, vp, _f64p, i64, _u64p, _f64p, _f64p]
     L.orc_proposal_set_adapt.argtypes = [vp, dbl]
+    L.orc_proposal_set_mass.argtypes = [vp, vp]
     L.orc_run_adapt.restype = i32
     L.orc_run_adapt.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, vp, vp, vp, i32, vp]
     L.orc_run.restype = i32
@@ -200,9 +201,12 @@ class HMC(_Proposal):
     """VanillaHMC(eps, Nsteps, grad, M=None): /root/reference/riemann/proposals/hamiltonian.py:55-91.
     Nsteps=1 is MALA."""
 
-    def __init__(self, eps, nsteps, d):
+    def __init__(self, eps, nsteps, d, M=None):
         self.d = d
         self._h = lib().orc_proposal_hmc(float(eps), int(nsteps), int(d))
+        if M is not None:   # hamiltonian.py:71-74
+            chM = _c(np.linalg.cholesky(np.atleast_2d(M)))
+            lib().orc_proposal_set_mass(self._h, chM.ctypes.data)
 
 
 # ----------------------------------------------------------------- sampler --

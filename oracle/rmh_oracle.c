@@ -457,6 +457,7 @@ typedef struct orc_proposal {
     double eps;       /* VanillaHMC: hamiltonian.py:60-74 (M=None only) */
     int nsteps;
     double adapt_target; /* > 0: AdaptScaleProposal mix-in, proposals/adaptive.py:11-35 */
+    double *chM;         /* cholesky(M) when a mass matrix is given, hamiltonian.py:71-74 */
 } orc_proposal;
 
 orc_proposal *orc_proposal_rw(const double *L, int d, double scale)
@@ -473,6 +474,13 @@ orc_proposal *orc_proposal_hmc(double eps, int nsteps, int d)
     return p;
 }
 
+/* VanillaHMC(..., M): chM = cholesky(M), lower, (d,d) row-major (hamiltonian.py:74) */
+void orc_proposal_set_mass(orc_proposal *p, const double *chM)
+{
+    free(p->chM);
+    p->chM = chM ? orc_dup(chM, (size_t)p->d * p->d) : NULL;
+}
+
 /* AdaptScaleRandomWalk (randomwalk.py:29-38, target 0.25) / AdaptScaleHMC
  * (hamiltonian.py:94-104, target 0.75): enable the scale adaptation */
 void orc_proposal_set_adapt(orc_proposal *p, double target) { p->adapt_target = target; }
@@ -481,6 +489,7 @@ void orc_proposal_free(orc_proposal *p)
 {
     if (!p) return;
     free(p->L);
+    free(p->chM);
     free(p);
 }
 
@@ -504,18 +513,61 @@ static double orc_propose1(const orc_proposal *p, const orc_model *m, const doub
     }
     double *mom = work, *g = work + d, *scr = work + 2 * d;
     const double eps = p->adapt_target > 0 ? chain_scale * p->eps : p->eps;
+    const double *C = p->chM;
+    double *psc = (double *)malloc(sizeof(double) * 3 * d), *p0 = psc + d, *tmp = psc + 2 * d;
+    /* p = normal(d); with a mass matrix p = chM p (hamiltonian.py:79-81) */
+    for (int i = 0; i < d; i++) {
+        if (C) {
+            double acc = 0;
+            for (int j = 0; j <= i; j++) acc += C[i * d + j] * xi[j];
+            p0[i] = acc;
+        } else p0[i] = xi[i];
+    }
+#define ORC_MINV(src, dst)                                                            \
+    do { /* dst = solve(M, src) = chM^-T chM^-1 src (hamiltonian.py:29,36) */           \
+        if (C) {                                                                      \
+            for (int i = 0; i < d; i++) {                                             \
+                double acc = (src)[i];                                                \
+                for (int j = 0; j < i; j++) acc -= C[i * d + j] * tmp[j];             \
+                tmp[i] = acc / C[i * d + i];                                          \
+            }                                                                         \
+            for (int i = d - 1; i >= 0; i--) {                                        \
+                double acc = tmp[i];                                                  \
+                for (int j = i + 1; j < d; j++) acc -= C[j * d + i] * (dst)[j];       \
+                (dst)[i] = acc / C[i * d + i];                                        \
+            }                                                                         \
+        } else                                                                        \
+            for (int i = 0; i < d; i++) (dst)[i] = (src)[i];                          \
+    } while (0)
     orc_grad1(m, th, g, scr);
-    for (int i = 0; i < d; i++) mom[i] = xi[i] + 0.5 * eps * g[i]; /* :27 */
-    for (int i = 0; i < d; i++) thp[i] = th[i] + eps * mom[i];     /* :30 */
+    for (int i = 0; i < d; i++) mom[i] = p0[i] + 0.5 * eps * g[i]; /* :27 */
+    ORC_MINV(mom, psc);
+    for (int i = 0; i < d; i++) thp[i] = th[i] + eps * psc[i];     /* :29-30 */
     for (int s = 0; s < p->nsteps - 1; s++) {                      /* :34-38 */
         orc_grad1(m, thp, g, scr);
         for (int i = 0; i < d; i++) mom[i] = mom[i] + eps * g[i];
-        for (int i = 0; i < d; i++) thp[i] = thp[i] + eps * mom[i];
+        ORC_MINV(mom, psc);
+        for (int i = 0; i < d; i++) thp[i] = thp[i] + eps * psc[i];
     }
     orc_grad1(m, thp, g, scr);
     for (int i = 0; i < d; i++) mom[i] = mom[i] + 0.5 * eps * g[i]; /* :40 */
     double k1 = 0, k0 = 0;
-    for (int i = 0; i < d; i++) { k1 += mom[i] * mom[i]; k0 += xi[i] * xi[i]; }
+    if (C) { /* p = solve(chM, p) for both momenta (:85-87) */
+        for (int pass = 0; pass < 2; pass++) {
+            const double *src = pass ? mom : p0;
+            double kk = 0;
+            for (int i = 0; i < d; i++) {
+                double acc = src[i];
+                for (int j = 0; j < i; j++) acc -= C[i * d + j] * tmp[j];
+                tmp[i] = acc / C[i * d + i];
+                kk += tmp[i] * tmp[i];
+            }
+            if (pass) k1 = kk; else k0 = kk;
+        }
+    } else
+        for (int i = 0; i < d; i++) { k1 += mom[i] * mom[i]; k0 += xi[i] * xi[i]; }
+#undef ORC_MINV
+    free(psc);
     return 0.5 * (k1 - k0); /* :89 */
 }
 

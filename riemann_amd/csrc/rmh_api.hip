@@ -135,6 +135,7 @@ struct rmh_proposal {
     std::vector<double> L;     // host copy of the Cholesky factor
     double *d_Ltiles = nullptr;
     bool dirty = true;
+    double *d_chM = nullptr, *d_V = nullptr, *d_VT = nullptr; // mass-matrix tile images (HMC)
 };
 
 struct rmh_state {
@@ -577,6 +578,32 @@ int rmh_proposal_hmc_create(double eps, int nsteps, int d, rmh_proposal_t *out)
     return RMH_OK;
 }
 
+int rmh_proposal_hmc_set_mass(rmh_proposal_t p, const double *chM)
+{
+    RMH_NEED_INIT();
+    if (!p || p->kind != kHMC) return fail(RMH_ERR_PARAM, "mass matrix: not an HMC proposal");
+    (void)hipFree(p->d_chM); (void)hipFree(p->d_V); (void)hipFree(p->d_VT);
+    p->d_chM = p->d_V = p->d_VT = nullptr;
+    if (!chM) return RMH_OK;
+    const int d = p->d, NT = p->NT;
+    if (NT < 0) return fail(RMH_ERR_PARAM, "hmc: d > 112 is not supported by the MFMA tile yet");
+    if (!lower_ok(chM, d)) return fail(RMH_ERR_PARAM, "mass matrix: chM must be a lower-triangular Cholesky factor");
+    std::vector<double> V((size_t)d * d, 0.0); // V = chM^-1 by forward substitution
+    for (int col = 0; col < d; ++col)
+        for (int i = col; i < d; ++i) {
+            double acc = (i == col) ? 1.0 : 0.0;
+            for (int j = col; j < i; ++j) acc -= chM[i * d + j] * V[j * d + col];
+            V[i * d + col] = acc / chM[i * d + i];
+        }
+    std::vector<double> a = pack_lower(chM, d, NT, 1.0), b = pack_lower(V.data(), d, NT, 1.0),
+                        c = pack_upper_T(V.data(), d, NT);
+    int rc;
+    if ((rc = upload(&p->d_chM, a.data(), a.size())) || (rc = upload(&p->d_V, b.data(), b.size())) ||
+        (rc = upload(&p->d_VT, c.data(), c.size())))
+        return rc;
+    return RMH_OK;
+}
+
 int rmh_proposal_set_scale(rmh_proposal_t p, double scale)
 {
     if (!p) return fail(RMH_ERR_PARAM, "null proposal");
@@ -607,6 +634,9 @@ int rmh_proposal_free(rmh_proposal_t p)
 {
     if (!p) return RMH_OK;
     (void)hipFree(p->d_Ltiles);
+    (void)hipFree(p->d_chM);
+    (void)hipFree(p->d_V);
+    (void)hipFree(p->d_VT);
     delete p;
     return RMH_OK;
 }
@@ -647,8 +677,9 @@ int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
                 e = launch_propose_rw(p->NT, ra, c, outp, g_stream); // logqratio = 0.0, randomwalk.py:26
             }
         } else {
-            HmcArgs ha{p->eps, p->nsteps};
-            if (m->kind == kGauss) e = launch_gauss_propose_hmc(m->NT, m->ga, ha, c, outp, lq, g_stream);
+            if (p->d_chM) rc = fail(RMH_ERR_PARAM, "propose: stand-alone HMC proposals with a mass matrix are not built");
+            HmcArgs ha{p->eps, p->nsteps, nullptr, nullptr, nullptr};
+            if (rc) {} else if (m->kind == kGauss) e = launch_gauss_propose_hmc(m->NT, m->ga, ha, c, outp, lq, g_stream);
             else if (m->kind == kLogReg) e = launch_logreg_propose_hmc(m->NT, m->la, ha, c, outp, lq, g_stream);
             else rc = fail(RMH_ERR_PARAM, "hmc: this model has no gradient");
         }
@@ -973,7 +1004,7 @@ int rmh_run(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t n
         else if (m->kind == kChangepoint) e = launch_cp_rw(m->k, m->ca, ra, c, r, g_stream);
         else return fail(RMH_ERR_PARAM, "run: random walk on the logistic model is not built yet");
     } else {
-        HmcArgs ha{p->eps, p->nsteps};
+        HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT};
         if (m->kind == kGauss) e = launch_gauss_hmc(m->NT, m->ga, ha, c, r, adapt, g_stream);
         else e = launch_logreg_hmc(m->NT, m->la, ha, c, r, adapt, g_stream);
     }

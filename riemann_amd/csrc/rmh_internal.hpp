@@ -73,6 +73,9 @@ struct RwArgs {
 struct HmcArgs {
     double eps;
     int nsteps;
+    // mass matrix M (hamiltonian.py:71-74), or null: tile images in GLOBAL memory
+    // (L2 resident; LDS is full) of chM = cholesky(M), V = chM^-1 and V^T
+    const double *chM, *V, *VT;
 };
 
 // tile counts of the triangular images
@@ -87,6 +90,7 @@ hipError_t launch_gauss_eval(int NT, const GaussArgs &m, const ChainArgs &c, int
 // `adapt`: run the AdaptScale* variant (c.adapt / c.adapt_target set, tile image unscaled)
 hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                            const RunArgs &r, bool adapt, hipStream_t st);
+// p.chM != null selects the mass-matrix variant
 hipError_t launch_gauss_hmc(int NT, const GaussArgs &m, const HmcArgs &p, const ChainArgs &c,
                             const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_propose_rw(int NT, const RwArgs &p, const ChainArgs &c, double *theta_p,

@@ -67,8 +67,12 @@ hipError_t launch_gauss_hmc(int NT, const GaussArgs &m, const HmcArgs &p, const 
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
         const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
-        if (adapt) return launch(k_run_hmc<M, 4, true>, c.nblocks, 4, lds, st, m, p, c, r);
-        return launch(k_run_hmc<M, 4, false>, c.nblocks, 4, lds, st, m, p, c, r);
+        if (p.chM) {
+            if (adapt) return launch(k_run_hmc<M, 4, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
+            return launch(k_run_hmc<M, 4, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
+        }
+        if (adapt) return launch(k_run_hmc<M, 4, true, false>, c.nblocks, 4, lds, st, m, p, c, r);
+        return launch(k_run_hmc<M, 4, false, false>, c.nblocks, 4, lds, st, m, p, c, r);
     })
 }
 
@@ -119,8 +123,12 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
         // s_waitcnt / barrier gaps of the stage loop: 0.52 -> 0.61 of the FP64 roof,
         // although the 256-register cap costs ~300 spilled registers outside the loop.
         constexpr int NW = (kNT >= 7) ? 8 : 4;
-        if (adapt) return launch(k_run_hmc<M, NW, true>, c.nblocks, NW, lds, st, m, p, c, r);
-        return launch(k_run_hmc<M, NW, false>, c.nblocks, NW, lds, st, m, p, c, r);
+        if (p.chM) { // mass-matrix variant: one wave per SIMD (register budget)
+            if (adapt) return launch(k_run_hmc<M, 4, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
+            return launch(k_run_hmc<M, 4, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
+        }
+        if (adapt) return launch(k_run_hmc<M, NW, true, false>, c.nblocks, NW, lds, st, m, p, c, r);
+        return launch(k_run_hmc<M, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);
     })
 }
 

@@ -64,6 +64,9 @@ struct Tile {
     // acc[i] += sum_{s <= 4i+3} A_lo(i,s) * B[s]     (A = lower-triangular image)
     // k-steps s >= ks = ceil(d/4) carry B[s] = 0 (padding coordinates) and are
     // skipped: only the last four can be, a wave-uniform test each.
+    // FENCE: pin the schedule every other k-step (images read from global memory:
+    // unfenced, the scheduler issues all ~110 loads of a product up front = 220 VGPRs).
+    template <bool FENCE = false>
     static RMH_DEV void mul_lower(const double *img_lane, const double (&B)[S], double4_t (&acc)[NT],
                                   int ks)
     {
@@ -74,10 +77,12 @@ struct Tile {
                 for (int i = s / 4; i < NT; ++i)
                     acc[i] = mfma(img_lane[lo(i, s) * 64], B[s], acc[i]);
             }
+            if (FENCE && (s & 1)) __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     // acc[i] += sum_{s >= 4i} A_up(i,s) * B[s]       (A = upper-triangular image)
+    template <bool FENCE = false>
     static RMH_DEV void mul_upper(const double *img_lane, const double (&B)[S], double4_t (&acc)[NT],
                                   int ks)
     {
@@ -88,6 +93,7 @@ struct Tile {
                 for (int i = 0; i <= s / 4; ++i)
                     acc[i] = mfma(img_lane[up(i, s) * 64], B[s], acc[i]);
             }
+            if (FENCE && (s & 1)) __builtin_amdgcn_sched_barrier(0);
         }
     }
 

@@ -35,6 +35,19 @@ struct Keep {
     }
 };
 
+// v <- T v for a triangular tile image T (lower, or upper when UPPER), in place
+template <int NT, bool UPPER>
+RMH_DEV void tri_apply(const double *img_lane, double (&v)[4 * NT], int ks)
+{
+    asm volatile("" ::: "memory"); // the image is loop-invariant: keep its loads here (no LICM)
+    double4_t acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+    if (UPPER) Tile<NT>::template mul_upper<true>(img_lane, v, acc, ks);
+    else Tile<NT>::template mul_lower<true>(img_lane, v, acc, ks);
+    Tile<NT>::unpack(acc, v);
+}
+
 // AdaptScaleProposal (riemann/proposals/adaptive.py:11-35) per chain: the adapt()
 // hook of sampler.py:88 after every step.  State in ch.adapt: rows Nsamples,
 // Naccepts, scale.  The first call compares with last_theta = None and therefore
@@ -145,7 +158,10 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
 // reference's re-evaluation, hamiltonian.py:27), and the last gradient call of
 // the trajectory (:40) is fused with the log_posterior call of sampler.py:82.
 // Current state and cached gradient live in global memory between iterations.
-template <class M, int NW, bool ADAPT>
+// MASS: VanillaHMC with a mass matrix M (hamiltonian.py:71-74, 80-81, 29, 36, 85-87):
+// p = chM xi;  q += eps M^-1 p with M^-1 p = V^T (V p), V = chM^-1;  K = |V p|^2 / 2.
+// The three triangular tile images are read straight from global memory (L2).
+template <class M, int NW, bool ADAPT, bool MASS>
 __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs pr, ChainArgs ch, RunArgs run)
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
@@ -187,12 +203,22 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
         }
         double k0 = 0.0;
 #pragma unroll
-        for (int s = 0; s < S; ++s) k0 += p[s] * p[s];
+        for (int s = 0; s < S; ++s) k0 += p[s] * p[s];   // K of the N(0,I) draw (= |chM^-1 p0|^2)
+        if (MASS) tri_apply<NT, false>(pr.chM + lane, p, ch.ks); // p0 = chM xi, :80-81
         T::load_state(ch.grad, ch.ld, c, g, gr);
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            p[s] = p[s] + heps * gr[s];     // hamiltonian.py:27
-            q[s] = q[s] + eps * p[s];       // :30
+        for (int s = 0; s < S; ++s) p[s] = p[s] + heps * gr[s];  // hamiltonian.py:27
+        if (MASS) {
+            double psc[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) psc[s] = p[s];
+            tri_apply<NT, false>(pr.V + lane, psc, ch.ks);       // M^-1 p = V^T V p, :29
+            tri_apply<NT, true>(pr.VT + lane, psc, ch.ks);
+#pragma unroll
+            for (int s = 0; s < S; ++s) q[s] = q[s] + eps * psc[s];
+        } else {
+#pragma unroll
+            for (int s = 0; s < S; ++s) q[s] = q[s] + eps * p[s]; // :30
         }
         // one evaluation site for all Nsteps gradient calls: the last one is
         // also the log_posterior call of sampler.py:82 and ends with the half kick
@@ -208,10 +234,21 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
 #pragma unroll
             for (int s = 0; s < S; ++s) p[s] = p[s] + ek * gr[s];
             if (!last) {
+                if (MASS) {
+                    double psc[S];
 #pragma unroll
-                for (int s = 0; s < S; ++s) q[s] = q[s] + eps * p[s]; // :37
+                    for (int s = 0; s < S; ++s) psc[s] = p[s];
+                    tri_apply<NT, false>(pr.V + lane, psc, ch.ks);   // :36
+                    tri_apply<NT, true>(pr.VT + lane, psc, ch.ks);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) q[s] = q[s] + eps * psc[s];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) q[s] = q[s] + eps * p[s]; // :37
+                }
             }
         }
+        if (MASS) tri_apply<NT, false>(pr.V + lane, p, ch.ks);   // p = solve(chM, p), :87
         double k1 = 0.0;
 #pragma unroll
         for (int s = 0; s < S; ++s) k1 += p[s] * p[s];

@@ -8,6 +8,8 @@ the reference's own example passes it (examples/test_randomwalk.py:32-37).
 Unlike the reference module, importing this one does not import matplotlib."""
 import ctypes as C
 
+import numpy as np
+
 from .. import _lib
 from ..models.model import DeviceModel
 from .adaptive import AdaptScaleProposal
@@ -23,19 +25,24 @@ class VanillaHMC(DeviceProposal):
         if not isinstance(model, DeviceModel):
             raise TypeError("VanillaHMC on the MI355X back end needs the gradient of a device "
                             "Model: pass the Model or its grad_log_posterior method")
-        if M is not None:
-            raise NotImplementedError("a mass matrix M is not supported by the device kernels yet "
-                                      "(BASELINE configs run with M=None)")
         if int(Nsteps) != Nsteps or Nsteps < 1:
             raise _lib.ParameterError("Nsteps must be an integer >= 1")
         self.Nsteps, self.eps = int(Nsteps), eps
         self._mgradU = gradlogpost
-        self.M, self.chM = None, None
         self._model = model
         self.Npars = model.Npars
         h = C.c_void_p()
         _lib.call("rmh_proposal_hmc_create", float(eps), self.Nsteps, self.Npars, C.byref(h))
         self._h = h
+        if M is None:                                         # hamiltonian.py:71-74
+            self.M, self.chM = None, None
+        else:
+            self.M = np.atleast_2d(np.asarray(M, dtype=np.float64))
+            self.chM = np.linalg.cholesky(self.M)
+            if self.chM.shape != (self.Npars, self.Npars):
+                raise _lib.ParameterError("M has shape {}, model has {} parameters"
+                                          .format(self.M.shape, self.Npars))
+            _lib.call("rmh_proposal_hmc_set_mass", self._h, _lib.as_f64(self.chM).ctypes.data)
 
     def _sync(self):
         _lib.call("rmh_proposal_set_eps", self._h, float(self.eps))

@@ -366,6 +366,31 @@ def g8_adapt_scale():
          target=np.float64(0.75), **r)
 
 
+# ---------------------------------------------- G9: HMC with a mass matrix M --
+def mass_matrix(d, seed):
+    g = np.random.default_rng(seed)
+    v = g.standard_normal(d) / np.sqrt(d)
+    return np.diag(np.linspace(0.5, 2.0, d)) + 0.8 * np.outer(v, v)
+
+
+def g9_hmc_mass():
+    """VanillaHMC(eps, Nsteps, grad, M): hamiltonian.py:71-74, 80-81, 29, 36, 85-87."""
+    Ct = corr100()
+    m = rbench.benchmark_gauss100d_corr
+    th0 = np.random.default_rng(9).standard_normal((4, 100)) @ np.linalg.cholesky(Ct).T
+    M = mass_matrix(100, 90)
+    r = run_reference(m, lambda: VanillaHMC(0.2, 4, m.grad_log_likelihood, M=M), th0, seed=91, T=16)
+    r.pop("xi")
+    save("g9_gauss100d_hmc_mass", M=M, eps=np.float64(0.2), nsteps=np.int64(4), **r)
+    X, y = logreg_data(256, 16, seed=2)
+    lm = LogRegModel(X, y, 100.0)
+    M2 = 0.25 * X.T @ X + np.eye(16) / 100.0
+    th0 = 0.1 * np.random.default_rng(4).standard_normal((4, 16))
+    r = run_reference(lm, lambda: VanillaHMC(0.5, 6, lm.grad_log_posterior, M=M2), th0, seed=92, T=32)
+    save("g9_logreg256x16_hmc_mass", X=X, y=y, tau2=np.float64(100.0), M=M2, eps=np.float64(0.5),
+         nsteps=np.int64(6), **r)
+
+
 if __name__ == "__main__":
     g0_rng()
     g1_gauss2d_rw()
@@ -376,3 +401,4 @@ if __name__ == "__main__":
     g6_edges(*args)
     g7_errors()
     g8_adapt_scale()
+    g9_hmc_mass()

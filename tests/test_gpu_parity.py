@@ -477,3 +477,42 @@ def test_adapt_scale_many_chains_vs_oracle(ra, orc):
     np.testing.assert_array_equal(s._chain_accept, acc)
     np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
     np.testing.assert_allclose(p.scale, ad[:, 2], rtol=1e-12)
+
+
+# ---------------------------------------------- HMC with a mass matrix (a-7)
+def test_g9_hmc_with_mass_matrix(ra):
+    from riemann_amd.models import LogisticRegression, benchmarks
+    from riemann_amd.proposals import VanillaHMC
+    z = load("g9_gauss100d_hmc_mass")
+    m = benchmarks.benchmark_gauss100d_corr
+    p = VanillaHMC(float(z["eps"]), int(z["nsteps"]), m.grad_log_likelihood, M=z["M"])
+    np.testing.assert_allclose(p.chM @ p.chM.T, z["M"], rtol=1e-12)
+    s = ra.Sampler(m, p, z["theta0"], seed=int(z["seed"]))
+    s.run(16)
+    check_run(z, s)
+    z = load("g9_logreg256x16_hmc_mass")
+    m = LogisticRegression(z["X"], z["y"], float(z["tau2"]))
+    s = ra.Sampler(m, VanillaHMC(float(z["eps"]), int(z["nsteps"]), m, M=z["M"]), z["theta0"],
+                   seed=int(z["seed"]))
+    s.run(32)
+    check_run(z, s)
+
+
+def test_hmc_mass_matrix_many_chains_vs_oracle(ra, orc):
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import VanillaHMC
+    g = np.random.default_rng(11)
+    for d, N in ((7, 50), (40, 130)):
+        A = g.standard_normal((d, d))
+        Cov = A @ A.T + d * np.eye(d)
+        B = g.standard_normal((d, d))
+        M = B @ B.T / d + np.eye(d)
+        th0 = g.standard_normal((N, d))
+        m = MultiGaussianDist(np.zeros(d), Cov)
+        s = ra.Sampler(m, VanillaHMC(0.7, 3, m.grad_log_likelihood, M=M), th0, seed=d)
+        s.run(20)
+        om = orc.Gaussian(np.zeros(d), Cov)
+        ht, hl, acc = oracle_run(orc, om, orc.HMC(0.7, 3, d, M=M), th0, d, 20)
+        np.testing.assert_array_equal(s._chain_accept, acc)
+        np.testing.assert_allclose(s._chain_thetas, ht, rtol=1e-8, atol=1e-10)
+        assert 0.05 < acc.mean() < 1.0

@@ -251,3 +251,13 @@ def test_g8_adaptive_scale_random_walk_and_hmc():
     _adapt_check(z, orc.Gaussian(np.zeros(100), Ct), orc.RandomWalk(float(z["prop_factor"]) * Ct), 64)
     z = load("g8_adapt_hmc_gauss100d")
     _adapt_check(z, orc.Gaussian(np.zeros(100), Ct), orc.HMC(float(z["eps0"]), int(z["nsteps"]), 100), 40)
+
+
+def test_g9_hmc_with_mass_matrix():
+    """VanillaHMC(eps, Nsteps, grad, M) (hamiltonian.py:71-91 with the M branches)."""
+    z = load("g9_gauss100d_hmc_mass")
+    check_run(z, *replay(z, orc.Gaussian(np.zeros(100), corr100()),
+                         orc.HMC(float(z["eps"]), int(z["nsteps"]), 100, M=z["M"])))
+    z = load("g9_logreg256x16_hmc_mass")
+    check_run(z, *replay(z, orc.LogReg(z["X"], z["y"], float(z["tau2"])),
+                         orc.HMC(float(z["eps"]), int(z["nsteps"]), 16, M=z["M"])))

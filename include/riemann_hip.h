@@ -82,6 +82,9 @@ int rmh_grad_log_posterior(rmh_model_t m, const double *theta, int64_t N, double
 /* ---- Proposal: riemann/proposals/proposal.py:1-26 ----------------------- */
 /* MetropolisRandomWalk(C), proposals/randomwalk.py:17-26.  L = cholesky(C). */
 int rmh_proposal_rw_create(const double *L, int d, double scale, rmh_proposal_t *out);
+/* pCN(C, rho), proposals/randomwalk.py:78-101.  L = cholesky(C).  (Gaussian model,
+ * fused run only.) */
+int rmh_proposal_pcn_create(const double *L, int d, double rho, rmh_proposal_t *out);
 /* VanillaHMC(eps, Nsteps, gradlogpost, M=None), proposals/hamiltonian.py:60-91;
  * the gradient is the device Model's.  Nsteps = 1 is MALA. */
 int rmh_proposal_hmc_create(double eps, int nsteps, int d, rmh_proposal_t *out);

@@ -60,6 +60,8 @@ def lib():
     L.orc_changepoint_indices.argtypes = [vp, _f64p, i64, _i32p]
     L.orc_proposal_rw.restype = vp
     L.orc_proposal_rw.argtypes = [_f64p, i32, dbl]
+    L.orc_proposal_pcn.restype = vp
+    L.orc_proposal_pcn.argtypes = [_f64p, i32, dbl]
     L.orc_proposal_hmc.restype = vp
     L.orc_proposal_hmc.argtypes = [dbl, i32, i32]
     L.orc_proposal_free.argtypes = [vp]
@@ -195,6 +197,15 @@ class RandomWalk(_Proposal):
         Lc = _c(np.linalg.cholesky(np.atleast_2d(Cov)))
         self.d = Lc.shape[0]
         self._h = lib().orc_proposal_rw(Lc, self.d, float(scale))
+
+
+class PCN(_Proposal):
+    """pCN(C, rho): /root/reference/riemann/proposals/randomwalk.py:78-101."""
+
+    def __init__(self, Cov, rho):
+        Lc = _c(np.linalg.cholesky(np.atleast_2d(Cov)))
+        self.d = Lc.shape[0]
+        self._h = lib().orc_proposal_pcn(Lc, self.d, float(rho))
 
 
 class HMC(_Proposal):

@@ -449,7 +449,7 @@ void orc_changepoint_indices(const orc_model *m, const double *theta, int64_t N,
 /* ------------------------------------------------------------------------- */
 /* 3. Proposals                                                                */
 /* ------------------------------------------------------------------------- */
-enum { ORC_RW = 1, ORC_HMC = 2 };
+enum { ORC_RW = 1, ORC_HMC = 2, ORC_PCN = 3 };
 
 typedef struct orc_proposal {
     int kind, d;
@@ -458,12 +458,22 @@ typedef struct orc_proposal {
     int nsteps;
     double adapt_target; /* > 0: AdaptScaleProposal mix-in, proposals/adaptive.py:11-35 */
     double *chM;         /* cholesky(M) when a mass matrix is given, hamiltonian.py:71-74 */
+    double rho, rho_c;   /* pCN, randomwalk.py:83-87 */
 } orc_proposal;
 
 orc_proposal *orc_proposal_rw(const double *L, int d, double scale)
 {
     orc_proposal *p = (orc_proposal *)calloc(1, sizeof(*p));
     p->kind = ORC_RW; p->d = d; p->L = orc_dup(L, (size_t)d * d); p->scale = scale;
+    return p;
+}
+
+/* pCN(C, rho): proposals/randomwalk.py:78-101.  L = cholesky(C). */
+orc_proposal *orc_proposal_pcn(const double *L, int d, double rho)
+{
+    orc_proposal *p = (orc_proposal *)calloc(1, sizeof(*p));
+    p->kind = ORC_PCN; p->d = d; p->L = orc_dup(L, (size_t)d * d); p->scale = 1.0;
+    p->rho = rho; p->rho_c = sqrt(1 - rho * rho);
     return p;
 }
 
@@ -510,6 +520,27 @@ static double orc_propose1(const orc_proposal *p, const orc_model *m, const doub
             thp[i] = th[i] + scale * acc;
         }
         return 0.0;
+    }
+    if (p->kind == ORC_PCN) { /* randomwalk.py:89-101 */
+        double *ufw = work, *urv = work + d;
+        for (int i = 0; i < d; i++) {
+            double acc = 0;
+            for (int j = 0; j < d; j++) acc += p->L[i * d + j] * xi[j];
+            thp[i] = p->rho * th[i] + p->rho_c * acc;
+        }
+        double sf = 0, sr = 0;
+        for (int i = 0; i < d; i++) { /* u = solve(L * rho_c, dtheta), forward substitution */
+            double af = thp[i] - p->rho * th[i], ar = th[i] - p->rho * thp[i];
+            for (int j = 0; j < i; j++) {
+                af -= p->L[i * d + j] * p->rho_c * ufw[j];
+                ar -= p->L[i * d + j] * p->rho_c * urv[j];
+            }
+            ufw[i] = af / (p->L[i * d + i] * p->rho_c);
+            urv[i] = ar / (p->L[i * d + i] * p->rho_c);
+            sf += ufw[i] * ufw[i];
+            sr += urv[i] * urv[i];
+        }
+        return -0.5 * (sf - sr);
     }
     double *mom = work, *g = work + d, *scr = work + 2 * d;
     const double eps = p->adapt_target > 0 ? chain_scale * p->eps : p->eps;

@@ -39,6 +39,7 @@ SIGNATURES = {
     "rmh_log_posterior": [_vp, _f64, _i64, _f64],
     "rmh_grad_log_posterior": [_vp, _f64, _i64, _f64],
     "rmh_proposal_rw_create": [_f64, _int, _dbl, _pvp],
+    "rmh_proposal_pcn_create": [_f64, _int, _dbl, _pvp],
     "rmh_proposal_hmc_create": [_dbl, _int, _int, _pvp],
     "rmh_proposal_hmc_set_mass": [_vp, _vp],
     "rmh_proposal_set_scale": [_vp, _dbl],

@@ -130,7 +130,7 @@ struct rmh_model {
 
 struct rmh_proposal {
     int kind = 0, d = 0, NT = 0;
-    double scale = 1.0, eps = 0.0, adapt_target = 0.0;
+    double scale = 1.0, eps = 0.0, adapt_target = 0.0, rho = 0.0;
     int nsteps = 0;
     std::vector<double> L;     // host copy of the Cholesky factor
     double *d_Ltiles = nullptr;
@@ -178,9 +178,24 @@ ChainArgs chain_args(const rmh_state *s)
 
 int sync_proposal(rmh_proposal *p)
 {
-    if (p->kind != kRW || !p->dirty) return RMH_OK;
-    // adaptive variant: the chains carry their own scale, the image stays unscaled
-    std::vector<double> img = pack_lower(p->L.data(), p->d, p->NT, p->adapt_target > 0 ? 1.0 : p->scale);
+    if ((p->kind != kRW && p->kind != kPCN) || !p->dirty) return RMH_OK;
+    // adaptive variant: the chains carry their own scale, the image stays unscaled;
+    // pCN: the image is rho_c * L (randomwalk.py:86, 93)
+    const double sc = p->kind == kPCN ? std::sqrt(1 - p->rho * p->rho) : p->adapt_target > 0 ? 1.0 : p->scale;
+    std::vector<double> img = pack_lower(p->L.data(), p->d, p->NT, sc);
+    if (p->kind == kPCN && !p->d_V) { // (rho_c L)^-1 for the two solves of randomwalk.py:97-98
+        const int d = p->d;
+        std::vector<double> V((size_t)d * d, 0.0);
+        for (int col = 0; col < d; ++col)
+            for (int i = col; i < d; ++i) {
+                double acc = (i == col) ? 1.0 : 0.0;
+                for (int j = col; j < i; ++j) acc -= sc * p->L[i * d + j] * V[j * d + col];
+                V[i * d + col] = acc / (sc * p->L[i * d + i]);
+            }
+        std::vector<double> vimg = pack_lower(V.data(), d, p->NT, 1.0);
+        int rc = upload(&p->d_V, vimg.data(), vimg.size());
+        if (rc) return rc;
+    }
     if (!p->d_Ltiles) {
         int rc = dev_alloc(&p->d_Ltiles, img.size());
         if (rc) return rc;
@@ -563,6 +578,17 @@ int rmh_proposal_rw_create(const double *L, int d, double scale, rmh_proposal_t 
     return RMH_OK;
 }
 
+int rmh_proposal_pcn_create(const double *L, int d, double rho, rmh_proposal_t *out)
+{
+    RMH_NEED_INIT();
+    if (!(rho > -1.0 && rho < 1.0)) return fail(RMH_ERR_PARAM, "pCN: need |rho| < 1");
+    int rc = rmh_proposal_rw_create(L, d, 1.0, out);
+    if (rc) return rc;
+    (*out)->kind = kPCN;
+    (*out)->rho = rho;
+    return RMH_OK;
+}
+
 int rmh_proposal_hmc_create(double eps, int nsteps, int d, rmh_proposal_t *out)
 {
     RMH_NEED_INIT();
@@ -670,10 +696,12 @@ int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
     hipError_t e = hipMemsetAsync(lq, 0, (size_t)s.ld * sizeof(double), g_stream);
     if (e == hipSuccess) e = hipMemsetAsync(outp, 0, (size_t)s.dp * s.ld * sizeof(double), g_stream);
     if (e == hipSuccess) {
-        if (p->kind == kRW) {
+        if (p->kind == kPCN) {
+            rc = fail(RMH_ERR_PARAM, "propose: stand-alone pCN proposals are not built");
+        } else if (p->kind == kRW) {
             rc = sync_proposal(p);
             if (!rc) {
-                RwArgs ra{p->d_Ltiles, nullptr};
+                RwArgs ra{p->d_Ltiles, nullptr, 0.0};
                 e = launch_propose_rw(p->NT, ra, c, outp, g_stream); // logqratio = 0.0, randomwalk.py:26
             }
         } else {
@@ -998,8 +1026,13 @@ int rmh_run(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t n
     r.h_accept = h ? h->accept : nullptr;
     RMH_HIP(hipEventRecord(g_ev0, g_stream));
     hipError_t e = hipSuccess;
-    if (p->kind == kRW) {
-        RwArgs ra{p->d_Ltiles, nullptr};
+    if (p->kind == kPCN) {
+        RwArgs ra{p->d_Ltiles, p->d_V, p->rho};
+        if (m->kind != kGauss) return fail(RMH_ERR_PARAM, "run: pCN is built for the Gaussian model only");
+        if (adapt) return fail(RMH_ERR_PARAM, "run: AdaptScalepCN is not built");
+        e = launch_gauss_pcn(m->NT, m->ga, ra, c, r, g_stream);
+    } else if (p->kind == kRW) {
+        RwArgs ra{p->d_Ltiles, nullptr, 0.0};
         if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
         else if (m->kind == kChangepoint) e = launch_cp_rw(m->k, m->ca, ra, c, r, g_stream);
         else return fail(RMH_ERR_PARAM, "run: random walk on the logistic model is not built yet");

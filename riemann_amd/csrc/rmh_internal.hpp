@@ -7,7 +7,7 @@
 namespace rmh {
 
 enum ModelKind { kGauss = 1, kLogReg = 2, kChangepoint = 3 };
-enum ProposalKind { kRW = 1, kHMC = 2 };
+enum ProposalKind { kRW = 1, kHMC = 2, kPCN = 3 };
 
 // ---- device-side argument blocks (passed by value to the kernels) ----------
 struct GaussArgs {
@@ -66,8 +66,9 @@ struct RunArgs {
 };
 
 struct RwArgs {
-    const double *Ltiles; // lower-triangular tile image of scale*L (MFMA kernels)
-    const double *Ldense; // (d,d) row-major scale*L (lane kernels)
+    const double *Ltiles; // lower-triangular tile image of scale*L (rho_c*L for pCN), staged in LDS
+    const double *Vtiles; // pCN: tile image of (rho_c*L)^-1, read from global memory (L2)
+    double rho;           // pCN (proposals/randomwalk.py:83-86)
 };
 
 struct HmcArgs {
@@ -90,6 +91,8 @@ hipError_t launch_gauss_eval(int NT, const GaussArgs &m, const ChainArgs &c, int
 // `adapt`: run the AdaptScale* variant (c.adapt / c.adapt_target set, tile image unscaled)
 hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                            const RunArgs &r, bool adapt, hipStream_t st);
+hipError_t launch_gauss_pcn(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
+                            const RunArgs &r, hipStream_t st);
 // p.chM != null selects the mass-matrix variant
 hipError_t launch_gauss_hmc(int NT, const GaussArgs &m, const HmcArgs &p, const ChainArgs &c,
                             const RunArgs &r, bool adapt, hipStream_t st);

@@ -56,8 +56,18 @@ hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const Ch
         // eight waves give every SIMD a second wavefront to cover the s_waitcnt
         // stalls (LDS table reads of the normals, state/record traffic): +16 %
         constexpr int NW = (kNT >= 7) ? 8 : 4;
-        if (adapt) return launch(k_run_rw<M, NW, true>, c.nblocks, NW, lds, st, m, p, c, r);
-        return launch(k_run_rw<M, NW, false>, c.nblocks, NW, lds, st, m, p, c, r);
+        if (adapt) return launch(k_run_rw<M, NW, true, false>, c.nblocks, NW, lds, st, m, p, c, r);
+        return launch(k_run_rw<M, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);
+    })
+}
+
+hipError_t launch_gauss_pcn(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
+                            const RunArgs &r, hipStream_t st)
+{
+    RMH_NT_DISPATCH(NT, {
+        using M = GaussModel<kNT>;
+        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false) + kIcdfDoubles);
+        return launch(k_run_rw<M, 4, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
     })
 }
 

@@ -82,7 +82,10 @@ struct AdaptScale {
 // MFMAs, it only covers s_waitcnt stalls.  The chain state, the candidate and the
 // normals all stay in registers (<= 256 at two waves per SIMD) and the only HBM
 // traffic of an iteration is the recorded sample.
-template <class M, int NW, bool ADAPT>
+// PCN: preconditioned Crank-Nicolson (proposals/randomwalk.py:78-101):
+//   theta' = rho theta + rho_c L xi;  logqratio = -(|u_fwd|^2 - |u_rev|^2)/2 with
+//   u = (rho_c L)^-1 dtheta for dtheta_fwd = theta' - rho theta, dtheta_rev = theta - rho theta'.
+template <class M, int NW, bool ADAPT, bool PCN = false>
 __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
@@ -121,8 +124,29 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
         T::normals(rng, ch.M, ch.d, g, tab, xi);
         // theta' = theta + scale * L xi        (randomwalk.py:26; logqratio = 0.0)
         double4_t acc[NT];
-        double thp[S], lpp, dummy[S], parts[2];
-        if (ADAPT) { // the chain's own adapted scale: theta + scale * (L xi), image unscaled
+        double thp[S], lpp, dummy[S], parts[2], logq = 0.0;
+        if (PCN) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) thp[s] = pr.rho * th[s];
+            T::pack(thp, acc);
+            T::mul_lower(Limg + lane, xi, acc, ch.ks);   // image holds rho_c * L
+            T::unpack(acc, thp);
+            double ufw[S], urv[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                ufw[s] = thp[s] - pr.rho * th[s];        // randomwalk.py:95-96
+                urv[s] = th[s] - pr.rho * thp[s];
+            }
+            tri_apply<NT, false>(pr.Vtiles + lane, ufw, ch.ks);
+            tri_apply<NT, false>(pr.Vtiles + lane, urv, ch.ks);
+            double sf = 0.0, sr = 0.0;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                sf += ufw[s] * ufw[s];
+                sr += urv[s] * urv[s];
+            }
+            logq = -0.5 * (sum4(sf) - sum4(sr));         // :99-100
+        } else if (ADAPT) { // the chain's own adapted scale: theta + scale * (L xi), image unscaled
 #pragma unroll
             for (int i = 0; i < NT; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
             T::mul_lower(Limg + lane, xi, acc, ch.ks);
@@ -136,7 +160,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
         }
         M::template eval<false>(mlds, m, false, lane, thp, lpp, dummy, parts);
         const double u = T::accept_uniform(rng, g, cl);
-        const bool acc_ok = mh_accept(lpp, lp, 0.0, u);
+        const bool acc_ok = mh_accept(lpp, lp, logq, u);
 #pragma unroll
         for (int s = 0; s < S; ++s) th[s] = acc_ok ? thp[s] : th[s];
         lp = acc_ok ? lpp : lp;

@@ -35,3 +35,19 @@ class AdaptScaleRandomWalk(AdaptScaleProposal, MetropolisRandomWalk):
 
     def _sync(self):
         pass  # the scale is the chains' state, not the proposal's
+
+
+class pCN(DeviceProposal):
+    """A preconditioned Crank-Nicolson proposal (randomwalk.py:78-101):
+    theta' = rho theta + sqrt(1-rho^2) L xi with its asymmetric logqratio.
+    ``.scale``, ``.rho``, ``.rho_c``, ``.L`` as in the reference."""
+
+    def __init__(self, C_, rho):
+        self.scale = 1.0
+        self.rho = rho
+        self.rho_c = np.sqrt(1 - self.rho ** 2)
+        self.L = np.linalg.cholesky(np.atleast_2d(np.asarray(C_, dtype=np.float64)))
+        self.Npars = self.L.shape[0]
+        h = C.c_void_p()
+        _lib.call("rmh_proposal_pcn_create", _lib.as_f64(self.L), self.Npars, float(rho), C.byref(h))
+        self._h = h

@@ -391,6 +391,22 @@ def g9_hmc_mass():
          nsteps=np.int64(6), **r)
 
 
+# ----------------------------------------------------- G10: pCN --
+def g10_pcn():
+    """pCN(C, rho), proposals/randomwalk.py:78-101: asymmetric logqratio."""
+    from riemann.proposals.randomwalk import pCN
+    Ct = corr100()
+    m = rbench.benchmark_gauss100d_corr
+    th0 = np.random.default_rng(10).standard_normal((4, 100)) @ np.linalg.cholesky(Ct).T
+    r = run_reference(m, lambda: pCN(0.7 * Ct + 0.3 * np.eye(100), 0.995), th0, seed=100, T=32)
+    r.pop("xi")
+    save("g10_pcn_gauss100d", rho=np.float64(0.995), **r)
+    m2 = rbench.benchmark_gauss2d_corr
+    r = run_reference(m2, lambda: pCN(np.eye(2), 0.8), np.ones((4, 2)), seed=101, T=64)
+    save("g10_pcn_gauss2d", mu=np.zeros(2), C=0.1 * np.eye(2) + 0.9 * np.ones((2, 2)), Cprop=np.eye(2),
+         rho=np.float64(0.8), **r)
+
+
 if __name__ == "__main__":
     g0_rng()
     g1_gauss2d_rw()
@@ -402,3 +418,4 @@ if __name__ == "__main__":
     g7_errors()
     g8_adapt_scale()
     g9_hmc_mass()
+    g10_pcn()

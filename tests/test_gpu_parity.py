@@ -516,3 +516,31 @@ def test_hmc_mass_matrix_many_chains_vs_oracle(ra, orc):
         np.testing.assert_array_equal(s._chain_accept, acc)
         np.testing.assert_allclose(s._chain_thetas, ht, rtol=1e-8, atol=1e-10)
         assert 0.05 < acc.mean() < 1.0
+
+
+# ------------------------------------------------------- pCN
+def test_g10_pcn(ra, orc):
+    from riemann_amd.models import MultiGaussianDist, benchmarks
+    from riemann_amd.proposals import pCN
+    z = load("g10_pcn_gauss100d")
+    Ct = corr100()
+    p = pCN(0.7 * Ct + 0.3 * np.eye(100), float(z["rho"]))
+    assert p.rho_c == np.sqrt(1 - p.rho ** 2) and p.scale == 1.0
+    s = ra.Sampler(benchmarks.benchmark_gauss100d_corr, p, z["theta0"], seed=int(z["seed"]))
+    s.run(32)
+    check_run(z, s)
+    z = load("g10_pcn_gauss2d")
+    s = ra.Sampler(MultiGaussianDist(z["mu"], z["C"]), pCN(z["Cprop"], float(z["rho"])), z["theta0"],
+                   seed=int(z["seed"]))
+    s.run(64)
+    check_run(z, s)
+    g = np.random.default_rng(12)                     # many chains vs the oracle
+    d, N = 33, 200
+    A = g.standard_normal((d, d))
+    Cov = A @ A.T + d * np.eye(d)
+    th0 = g.standard_normal((N, d)) * 3
+    s = ra.Sampler(MultiGaussianDist(np.zeros(d), Cov), pCN(Cov, 0.9), th0, seed=5)
+    s.run(25)
+    ht, hl, acc = oracle_run(orc, orc.Gaussian(np.zeros(d), Cov), orc.PCN(Cov, 0.9), th0, 5, 25)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)

@@ -261,3 +261,13 @@ def test_g9_hmc_with_mass_matrix():
     z = load("g9_logreg256x16_hmc_mass")
     check_run(z, *replay(z, orc.LogReg(z["X"], z["y"], float(z["tau2"])),
                          orc.HMC(float(z["eps"]), int(z["nsteps"]), 16, M=z["M"])))
+
+
+def test_g10_pcn():
+    """pCN(C, rho) (proposals/randomwalk.py:78-101)."""
+    z = load("g10_pcn_gauss100d")
+    Ct = corr100()
+    check_run(z, *replay(z, orc.Gaussian(np.zeros(100), Ct),
+                         orc.PCN(0.7 * Ct + 0.3 * np.eye(100), float(z["rho"]))))
+    z = load("g10_pcn_gauss2d")
+    check_run(z, *replay(z, orc.Gaussian(z["mu"], z["C"]), orc.PCN(z["Cprop"], float(z["rho"]))))

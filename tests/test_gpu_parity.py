@@ -544,3 +544,52 @@ def test_g10_pcn(ra, orc):
     ht, hl, acc = oracle_run(orc, orc.Gaussian(np.zeros(d), Cov), orc.PCN(Cov, 0.9), th0, 5, 25)
     np.testing.assert_array_equal(s._chain_accept, acc)
     np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+
+
+# ------------------------------------------------------------ edge cases
+def test_edge_cases_run_lengths_and_sizes(ra, orc):
+    """Nsamples = 0, Nburn > Nsamples (empty history, then no current state, as the
+    reference's empty lists), d = 1, d = 112 (largest tile), Nthin > Nsamples."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    m, p = MultiGaussianDist(np.zeros(2), np.eye(2)), MetropolisRandomWalk(np.eye(2))
+    s = ra.Sampler(m, p, np.ones((3, 2)), seed=1)
+    s.run(0)
+    assert s._chain_thetas.shape == (1, 3, 2) and s._chain_accept.shape == (0, 3)
+    np.testing.assert_array_equal(s._chain_thetas[0], np.ones((3, 2)))
+    s.run(5, 0, 7)                                   # [0::7] of 6 states keeps state 0 only ...
+    assert s._chain_thetas.shape == (1, 3, 2)
+    np.testing.assert_array_equal(s.current_state()[0], np.ones((3, 2)))   # ... which stays current
+    s.run(3, 10, 1)                                  # Nburn > Nsamples: nothing kept
+    assert s._chain_thetas.shape == (0, 3, 2)
+    with pytest.raises(IndexError):
+        s.current_state()
+    with pytest.raises(IndexError):
+        s.run(1)
+    for d in (1, 112):
+        g = np.random.default_rng(d)
+        A = g.standard_normal((d, d))
+        Cov = A @ A.T + d * np.eye(d)
+        th0 = g.standard_normal((20, d))
+        s = ra.Sampler(MultiGaussianDist(np.zeros(d), Cov), MetropolisRandomWalk(0.1 * Cov), th0, seed=d)
+        s.run(15)
+        ht, hl, acc = oracle_run(orc, orc.Gaussian(np.zeros(d), Cov), orc.RandomWalk(0.1 * Cov), th0, d, 15)
+        np.testing.assert_array_equal(s._chain_accept, acc)
+        np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    with pytest.raises(ra.ParameterError):
+        MultiGaussianDist(np.zeros(113), np.eye(113))   # beyond the largest tile: loud, not wrong
+
+
+def test_non_finite_start_states(ra, orc):
+    """theta0 with inf / nan: log_posterior -> -inf (model.py:49-52), NaN ratio accepts."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    Cov = np.array([[2.0, 0.3], [0.3, 1.0]])
+    th0 = np.array([[np.inf, 0.0], [np.nan, 1.0], [1e200, -1e200], [0.5, 0.5]])
+    s = ra.Sampler(MultiGaussianDist(np.zeros(2), Cov), MetropolisRandomWalk(np.eye(2)), th0, seed=3)
+    assert list(np.isinf(s._chain_logpost[0])) == [True, True, True, False]
+    s.run(6)
+    ht, hl, acc = oracle_run(orc, orc.Gaussian(np.zeros(2), Cov), orc.RandomWalk(np.eye(2)), th0, 3, 6)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_array_equal(np.isfinite(s._chain_logpost), np.isfinite(hl))
+    np.testing.assert_array_equal(np.isnan(s._chain_thetas), np.isnan(ht))

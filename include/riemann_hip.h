@@ -145,6 +145,22 @@ int rmh_history_free(rmh_history_t h);
 int rmh_run(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t nburn,
             int64_t nthin, rmh_history_t h);
 
+/* ---- pooling the chains of several GPUs (no reference counterpart:
+ *      riemann/README.md:21-23 only states the aspiration) ---------------------
+ * One process per GPU.  Rank 0 calls rmh_comm_unique_id and ships the 128 bytes to
+ * the other ranks (any channel); every rank then calls rmh_comm_init.  RCCL is
+ * dlopen'ed on first use.  Both collectives run on the library's stream, outside
+ * the sampling loop. */
+int rmh_comm_unique_id(uint8_t *id128);
+int rmh_comm_init(const uint8_t *id128, int nranks, int rank);
+int rmh_comm_destroy(void);
+/* all-gather of the ranks' current states: pooled (nranks * N, d), rank-major;
+ * every rank must hold the same number of chains N */
+int rmh_allgather_samples(rmh_state_t s, double *pooled);
+/* all-reduce (sum) of [count, sum_p theta_p, sum theta_p theta_q]: moments has
+ * 1 + d + d*d entries; pooled mean and covariance follow on the host */
+int rmh_allreduce_moments(rmh_state_t s, double *moments);
+
 /* ---- test hooks ---------------------------------------------------------- */
 /* the stream as the reference consumes it: xi (T,N,d), u (T,N) for chains
  * chain0..chain0+N-1, generated on the device */

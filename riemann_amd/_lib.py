@@ -63,6 +63,11 @@ SIGNATURES = {
     "rmh_history_device_ptrs": [_vp, _pvp, _pvp, _pvp, C.POINTER(_i64)],
     "rmh_history_free": [_vp],
     "rmh_run": [_vp, _vp, _vp, _i64, _i64, _i64, _vp],
+    "rmh_comm_unique_id": [_u8],
+    "rmh_comm_init": [_u8, _int, _int],
+    "rmh_comm_destroy": [],
+    "rmh_allgather_samples": [_vp, _f64],
+    "rmh_allreduce_moments": [_vp, _f64],
     "rmh_debug_rng_stream": [_u64s, _u64s, _i64, _int, _int, _f64, _f64],
     "rmh_debug_mfma": [_f64, _f64, _f64, _f64],
 }

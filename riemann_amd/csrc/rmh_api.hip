@@ -307,6 +307,23 @@ void rng_from_device_layout(const std::vector<uint64_t> &dev, int64_t N, int64_t
 
 } // namespace
 
+// hooks for rmh_comm.hip
+namespace rmh {
+int comm_fail(int code, const std::string &msg) { return fail(code, msg); }
+hipStream_t comm_stream() { return g_stream; }
+int comm_state_info(rmh_state_t s, double **theta, int64_t *N, int64_t *ld, int *d, int *dp)
+{
+    if (!s) return fail(RMH_ERR_PARAM, "null state");
+    if (!s->valid) return fail(RMH_ERR_STATE, "state: no current state (empty history)");
+    *theta = s->theta;
+    *N = s->N;
+    *ld = s->ld;
+    *d = s->d;
+    *dp = s->dp;
+    return RMH_OK;
+}
+} // namespace rmh
+
 // ------------------------------------------------------------------ context
 extern "C" {
 
@@ -320,7 +337,8 @@ int rmh_device_count(int *count)
 
 int rmh_init(int device)
 {
-    if (g_init && device == g_device) return RMH_OK;
+    if (g_init && (device == g_device || device < 0)) return RMH_OK; // device < 0: "whatever is bound"
+    if (device < 0) return fail(RMH_ERR_STATE, "rmh_init: no device bound yet");
     if (g_init) return fail(RMH_ERR_STATE, "rmh_init: already bound to another device");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

@@ -1,0 +1,190 @@
+// rmh_comm.hip -- pooling the chains of several GPUs for diagnostics: one RCCL
+// all-gather of the ranks' state blocks and one all-reduce of their moment
+// accumulators over xGMI.  Not in the sampling loop.
+// The reference has nothing distributed (README.md:21-23).
+//
+// librccl is opened with dlopen at the first call, so that the sampling entry
+// points carry no link-time dependency on it.
+#include "../../include/riemann_hip.h"
+#include "rmh_internal.hpp"
+#include "rmh_mfma.hpp"
+
+#include <cstring>
+#include <dlfcn.h>
+#include <string>
+
+namespace rmh {
+int comm_fail(int code, const std::string &msg); // rmh_api.hip
+hipStream_t comm_stream();
+int comm_state_info(rmh_state_t s, double **theta, int64_t *N, int64_t *ld, int *d, int *dp);
+} // namespace rmh
+using namespace rmh;
+
+namespace {
+
+typedef struct { char internal[128]; } nccl_uid_t;
+typedef void *nccl_comm_t;
+enum { kNcclFloat64 = 8, kNcclSum = 0 }; // rccl.h: ncclDataType_t / ncclRedOp_t
+
+struct Rccl {
+    void *so = nullptr;
+    int (*GetUniqueId)(nccl_uid_t *) = nullptr;
+    int (*CommInitRank)(nccl_comm_t *, int, nccl_uid_t, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*CommDestroy)(nccl_comm_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+} g_rccl;
+nccl_comm_t g_comm = nullptr;
+int g_nranks = 0, g_rank = 0;
+
+int load_rccl()
+{
+    if (g_rccl.so) return RMH_OK;
+    void *so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!so) so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!so) so = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!so) return comm_fail(RMH_ERR_HIP, std::string("cannot open librccl: ") + dlerror());
+#define SYM(field, name)                                                              \
+    *reinterpret_cast<void **>(&g_rccl.field) = dlsym(so, name);                      \
+    if (!g_rccl.field) return comm_fail(RMH_ERR_HIP, std::string("librccl lacks ") + name)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(AllGather, "ncclAllGather");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.so = so;
+    return RMH_OK;
+}
+
+#define RMH_NCCL(expr)                                                                        \
+    do {                                                                                      \
+        int r_ = (expr);                                                                      \
+        if (r_ != 0)                                                                          \
+            return comm_fail(RMH_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+// per-chain-block partial moments: out[0] += n, out[1+p] += sum_c theta[p][c],
+// out[1+d+p*d+q] += sum_c theta[p][c] theta[q][c]  -- one workgroup per (p, q)
+__global__ void k_moments(const double *theta, int64_t N, int64_t ld, int d, double *out)
+{
+    __shared__ double red[4];
+    const int p = blockIdx.x / d, q = blockIdx.x % d;
+    double acc = 0.0, accp = 0.0;
+    for (int64_t c = threadIdx.x; c < N; c += blockDim.x) {
+        const double a = theta[(int64_t)p * ld + c];
+        acc += a * theta[(int64_t)q * ld + c];
+        accp += a;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        double v = pass ? accp : acc;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double t = red[0] + red[1] + red[2] + red[3];
+            if (pass == 0) out[1 + d + p * d + q] = t;
+            else if (q == 0) out[1 + p] = t;
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = (double)N;
+}
+
+} // namespace
+
+extern "C" {
+
+int rmh_comm_unique_id(uint8_t *id128)
+{
+    int rc = load_rccl();
+    if (rc) return rc;
+    nccl_uid_t id;
+    RMH_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id128, id.internal, 128);
+    return RMH_OK;
+}
+
+int rmh_comm_init(const uint8_t *id128, int nranks, int rank)
+{
+    int rc = rmh_init(-1); // the device must be bound already
+    if (rc) return rc;
+    if ((rc = load_rccl())) return rc;
+    if (g_comm) return comm_fail(RMH_ERR_STATE, "rmh_comm_init: communicator exists");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return comm_fail(RMH_ERR_PARAM, "rmh_comm_init: bad rank");
+    nccl_uid_t id;
+    memcpy(id.internal, id128, 128);
+    RMH_NCCL(g_rccl.CommInitRank(&g_comm, nranks, id, rank));
+    g_nranks = nranks;
+    g_rank = rank;
+    return RMH_OK;
+}
+
+int rmh_comm_destroy(void)
+{
+    if (g_comm) {
+        RMH_NCCL(g_rccl.CommDestroy(g_comm));
+        g_comm = nullptr;
+    }
+    return RMH_OK;
+}
+
+int rmh_allgather_samples(rmh_state_t s, double *pooled)
+{
+    if (!g_comm) return comm_fail(RMH_ERR_STATE, "rmh_allgather_samples: no communicator (rmh_comm_init)");
+    double *theta;
+    int64_t N, ld;
+    int d, dp;
+    int rc = comm_state_info(s, &theta, &N, &ld, &d, &dp);
+    if (rc) return rc;
+    hipStream_t st = comm_stream();
+    const size_t block = (size_t)dp * ld;
+    double *all = nullptr, *nd = nullptr;
+    hipError_t e = hipMalloc(&all, block * g_nranks * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&nd, (size_t)N * d * sizeof(double));
+    if (e != hipSuccess) {
+        (void)hipFree(all); (void)hipFree(nd);
+        return comm_fail(RMH_ERR_HIP, hipGetErrorString(e));
+    }
+    int r = g_rccl.AllGather(theta, all, block, kNcclFloat64, g_comm, st);
+    for (int k = 0; k < g_nranks && r == 0 && e == hipSuccess; ++k) {
+        e = launch_transpose_dn_to_nd(all + k * block, nd, N, d, ld, 1, st);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(pooled + (size_t)k * N * d, nd, (size_t)N * d * sizeof(double),
+                               hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(all); (void)hipFree(nd);
+    if (r != 0) return comm_fail(RMH_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
+    if (e != hipSuccess) return comm_fail(RMH_ERR_HIP, hipGetErrorString(e));
+    return RMH_OK;
+}
+
+int rmh_allreduce_moments(rmh_state_t s, double *moments)
+{
+    if (!g_comm) return comm_fail(RMH_ERR_STATE, "rmh_allreduce_moments: no communicator (rmh_comm_init)");
+    double *theta;
+    int64_t N, ld;
+    int d, dp;
+    int rc = comm_state_info(s, &theta, &N, &ld, &d, &dp);
+    if (rc) return rc;
+    hipStream_t st = comm_stream();
+    const size_t n = 1 + (size_t)d + (size_t)d * d;
+    double *acc = nullptr;
+    hipError_t e = hipMalloc(&acc, n * sizeof(double));
+    if (e != hipSuccess) return comm_fail(RMH_ERR_HIP, hipGetErrorString(e));
+    hipLaunchKernelGGL(k_moments, dim3((unsigned)(d * d)), dim3(256), 0, st, theta, N, ld, d, acc);
+    e = hipGetLastError();
+    int r = 0;
+    if (e == hipSuccess) r = g_rccl.AllReduce(acc, acc, n, kNcclFloat64, kNcclSum, g_comm, st);
+    if (e == hipSuccess && r == 0) e = hipMemcpyAsync(moments, acc, n * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && r == 0) e = hipStreamSynchronize(st);
+    (void)hipFree(acc);
+    if (r != 0) return comm_fail(RMH_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+    if (e != hipSuccess) return comm_fail(RMH_ERR_HIP, hipGetErrorString(e));
+    return RMH_OK;
+}
+
+} // extern "C"

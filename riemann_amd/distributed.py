@@ -66,3 +66,29 @@ def pooled_moments(local, group=None, device=None):
     n, s, ss = acc[0], acc[1: d + 1], acc[d + 1:].reshape(d, d)
     mean = s / n
     return mean, ss / n - np.outer(mean, mean)
+
+
+# ---- the same two collectives through the C ABI (RCCL opened by the library) ----
+def cabi_comm_init(rank, world, broadcast_bytes):
+    """Create the library's RCCL communicator.  ``broadcast_bytes(b)`` must return
+    rank 0's 128-byte id on every rank (e.g. a torch.distributed / file broadcast)."""
+    from . import _lib
+    uid = np.zeros(128, dtype=np.uint8)
+    if rank == 0:
+        _lib.call("rmh_comm_unique_id", uid)
+    uid = np.frombuffer(broadcast_bytes(uid.tobytes()), dtype=np.uint8).copy()
+    _lib.call("rmh_comm_init", uid, int(world), int(rank))
+
+
+def cabi_pool(sampler, world):
+    """(pooled states (world*N, d), pooled mean (d,), pooled covariance (d,d)) of a
+    Sampler's current states over all ranks: one ncclAllGather of the device state
+    blocks and one ncclAllReduce of the moment accumulators."""
+    from . import _lib
+    N, d = sampler.Nchains, sampler.Npars
+    pooled = np.empty((world * N, d))
+    _lib.call("rmh_allgather_samples", sampler._state, pooled)
+    mom = np.empty(1 + d + d * d)
+    _lib.call("rmh_allreduce_moments", sampler._state, mom)
+    mean = mom[1:1 + d] / mom[0]
+    return pooled, mean, mom[1 + d:].reshape(d, d) / mom[0] - np.outer(mean, mean)

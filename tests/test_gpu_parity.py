@@ -593,3 +593,33 @@ def test_non_finite_start_states(ra, orc):
     np.testing.assert_array_equal(s._chain_accept, acc)
     np.testing.assert_array_equal(np.isfinite(s._chain_logpost), np.isfinite(hl))
     np.testing.assert_array_equal(np.isnan(s._chain_thetas), np.isnan(ht))
+
+
+# ------------------------------------- C-ABI pooling over RCCL (world of one GPU)
+def test_rccl_pooling_entry_points_single_rank(ra):
+    """rmh_comm_* / rmh_allgather_samples / rmh_allreduce_moments with nranks = 1:
+    the all-gather returns this rank's states, the moments match numpy."""
+    from riemann_amd import _lib
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    g = np.random.default_rng(13)
+    N, d = 1000, 20
+    th0 = g.standard_normal((N, d))
+    s = ra.Sampler(MultiGaussianDist(np.zeros(d), np.eye(d)), MetropolisRandomWalk(0.1 * np.eye(d)),
+                   th0, seed=2)
+    s.run(5, record=False)
+    uid = np.zeros(128, dtype=np.uint8)
+    _lib.call("rmh_comm_unique_id", uid)
+    _lib.call("rmh_comm_init", uid, 1, 0)
+    try:
+        pooled = np.empty((N, d))
+        _lib.call("rmh_allgather_samples", s._state, pooled)
+        th, _ = s.current_state()
+        np.testing.assert_array_equal(pooled, th)
+        mom = np.empty(1 + d + d * d)
+        _lib.call("rmh_allreduce_moments", s._state, mom)
+        assert mom[0] == N
+        np.testing.assert_allclose(mom[1:1 + d], th.sum(axis=0), rtol=1e-12, atol=1e-10)
+        np.testing.assert_allclose(mom[1 + d:].reshape(d, d), th.T @ th, rtol=1e-12, atol=1e-10)
+    finally:
+        _lib.call("rmh_comm_destroy")

@@ -134,81 +134,12 @@ RMH_DEV double log_full(double x)
     return r;
 }
 
-// ---- link-function arithmetic of the logistic model (not part of the stream
-// spec: the oracle evaluates the same quantities with libm, tolerance-checked) --
-// 1/x for normal x by v_rcp_f64 + two Newton steps (<= 1 ulp; no IEEE fix-up)
-RMH_DEV double rcp_nr(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma_(fma_(-x, r, 1.0), r, r);
-    r = fma_(fma_(-x, r, 1.0), r, r);
-    return r;
-}
-
-// exp(-a) for a >= 0 (NaN propagates; underflows to 0 through ldexp)
-RMH_DEV double exp_neg(double a)
-{
-    constexpr double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01,
-                     LN2_LO = 1.90821492927058770002e-10;
-    a = (a > 800.0) ? 800.0 : a;
-    const double kd = __builtin_rint(-a * LOG2E);
-    double r = fma_(kd, -LN2_HI, -a);
-    r = fma_(kd, -LN2_LO, r); // |r| <= ln2/2
-    double p = 1.0 / 479001600.0;                       // 1/12!
-    p = fma_(p, r, 1.0 / 39916800.0);
-    p = fma_(p, r, 1.0 / 3628800.0);
-    p = fma_(p, r, 1.0 / 362880.0);
-    p = fma_(p, r, 1.0 / 40320.0);
-    p = fma_(p, r, 1.0 / 5040.0);
-    p = fma_(p, r, 1.0 / 720.0);
-    p = fma_(p, r, 1.0 / 120.0);
-    p = fma_(p, r, 1.0 / 24.0);
-    p = fma_(p, r, 1.0 / 6.0);
-    p = fma_(p, r, 0.5);
-    p = fma_(p, r, 1.0);
-    p = fma_(p, r, 1.0);
-    return __builtin_ldexp(p, (int)kd);
-}
-
-// log(u) for u in [1, 2] (same reduction and polynomial as log_core, reciprocal
-// instead of the IEEE division)
-RMH_DEV double log_1to2(double u)
-{
-    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
-                     Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
-                     Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
-                     Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                     Lg7 = 1.479819860511658591e-01;
-    const bool big = u > 1.4142135623730951;
-    const double m = big ? 0.5 * u : u;
-    const double dk = big ? 1.0 : 0.0;
-    const double f = m - 1.0;
-    const double s = f * rcp_nr(2.0 + f);
-    const double z = s * s;
-    const double w = z * z;
-    const double t1 = w * fma_(w, fma_(w, Lg6, Lg4), Lg2);
-    const double t2 = z * fma_(w, fma_(w, fma_(w, Lg7, Lg5), Lg3), Lg1);
-    const double R = t2 + t1;
-    const double hfsq = 0.5 * f * f;
-    return dk * ln2_hi - ((hfsq - fma_(s, hfsq + R, dk * ln2_lo)) - f);
-}
-
-// for one linear predictor eta: lse = log(1 + exp(eta)) and sg = sigmoid(eta)
-// (closed-form version: exp, reciprocal, log; ~63 f64 operations -- kept as the
-// reference form of the table version below)
-RMH_DEV void logistic_terms_closed(double eta, double &lse, double &sg)
-{
-    const double a = __builtin_fabs(eta);
-    const double e = exp_neg(a);          // in [0, 1]
-    const double u = 1.0 + e;
-    const double lo = e - (u - 1.0);      // rounding error of 1 + e, exact
-    const double t = rcp_nr(u);
-    const double l1p = fma_(lo, t, log_1to2(u)); // log1p(e)
-    lse = ((eta > 0.0) ? eta : 0.0) + l1p;
-    sg = (eta >= 0.0) ? t : e * t;
-}
-
-// Table version (tools/gen_logistic_table.py): |eta| in [0, 37.5) is cut into 150
+// ---- link function of the logistic model (not part of the stream spec: the
+// oracle evaluates the same quantities with libm, tolerance-checked) -------------
+// A closed-form version (Cody-Waite exp + v_rcp_f64 with two Newton steps + fdlibm
+// log, ~63 f64 operations per value) was measured first: 0.506 of the FP64 roof
+// against 0.517 for the table below at one wave per SIMD, 0.589 against 0.610 at two.
+// Table (tools/gen_logistic_table.py): |eta| in [0, 37.5) is cut into 150
 // intervals of width 1/4, each with two degree-9 polynomials in t = 2 frac(4|eta|) - 1:
 //   f = log1p(exp(-|eta|)),  s = sigmoid(-|eta|);  worst relative error 2.1e-16.
 // 20 fma + ~10 other operations and ten ds_read_b128 instead of exp + rcp + log:

@@ -114,9 +114,6 @@ struct CpModel {
     {
         const double sig = th[D - 1], sig2 = sig * sig;
         double ss = 0.0;
-#ifdef RMH_CP_UNROLL
-#pragma unroll RMH_CP_UNROLL
-#endif
         for (int i = g; i < m.n; i += 4) {
             const double x = xy[i], y = xy[m.n + i];
             int idx;

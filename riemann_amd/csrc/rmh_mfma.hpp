@@ -126,19 +126,6 @@ struct Tile {
     // Horner chains overlap (a single evaluation is latency-bound, ~400 cycles).
     static RMH_DEV void normals(Xo &rng, int M, int d, int g, const double *tab, double (&xi)[S])
     {
-#ifdef RMH_NORMALS_TWO_PASS
-        uint64_t w[S];
-#pragma unroll
-        for (int m = 0; m < S; ++m) {
-            w[m] = 0;
-            if (m < M) w[m] = xo_next(rng);
-        }
-#pragma unroll
-        for (int m = 0; m < S; ++m) {
-            const double z = normal_from_word(w[m], tab);
-            xi[m] = (4 * m + g < d) ? z : 0.0;
-        }
-#else
         constexpr int GRP = 4;
 #pragma unroll
         for (int m0 = 0; m0 < S; m0 += GRP) {
@@ -159,7 +146,6 @@ struct Tile {
                 for (int k = 0; k < GRP; ++k) xi[m0 + k] = 0.0;
             }
         }
-#endif
     }
 
     // the accept uniform: one word of sub-stream 0 (lanes g == 0), broadcast to

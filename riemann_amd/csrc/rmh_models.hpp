@@ -195,11 +195,7 @@ struct LogRegModel {
             for (int r = 0; r < 4; ++r) {
                 const double e = comp(eta, r), yv = yw[4 * r + g], wv = yw[16 + 4 * r + g];
                 double lse, sg;
-#ifdef RMH_LOGI_CLOSED
-                logistic_terms_closed(e, lse, sg);
-#else
                 logistic_terms(e, ltab, lse, sg);
-#endif
                 ll += wv * (yv * e - lse);
                 res[r] = wv * (yv - sg);
             }

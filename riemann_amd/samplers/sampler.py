@@ -141,6 +141,39 @@ class Sampler(object):
             self._host_logpost = np.empty((0, self.Nchains))
             self._host_accept = np.empty((0, self.Nchains), dtype=np.uint8)
 
+    # ------------------------------------------------------ checkpoint / resume --
+    def checkpoint(self, path):
+        """Write the chains' resumable state to ``path`` (.npz): current states,
+        random-stream states and, for adaptive proposals, the adaptation state.
+        The reference only resumes in-process (run() continues from the last state,
+        sampler.py:49-50)."""
+        th, lp = np.empty((self.Nchains, self.Npars)), np.empty(self.Nchains)
+        _lib.call("rmh_state_get", self._state, th.ctypes.data, lp.ctypes.data)
+        rng = np.empty((self.Nchains, 16), dtype=np.uint64)
+        _lib.call("rmh_state_get_rng", self._state, rng)
+        ad = np.empty((self.Nchains, 3))
+        _lib.call("rmh_state_get_adapt", self._state, ad)
+        np.savez(path, theta=th, logpost=lp, rng=rng, adapt=ad, single=np.bool_(self._single))
+
+    def restore(self, path):
+        """Load a checkpoint written by :meth:`checkpoint` into this Sampler (same
+        model, proposal and number of chains); the next run() continues the same
+        chains bit for bit."""
+        z = np.load(path)
+        if z["theta"].shape != (self.Nchains, self.Npars):
+            raise _lib.ParameterError("checkpoint holds states of shape {}, sampler has {}"
+                                      .format(z["theta"].shape, (self.Nchains, self.Npars)))
+        _lib.call("rmh_state_set_theta", self._state, _lib.as_f64(z["theta"]))
+        _lib.call("rmh_state_set_rng", self._state, np.ascontiguousarray(z["rng"], dtype=np.uint64))
+        _lib.call("rmh_state_set_adapt", self._state, _lib.as_f64(z["adapt"]))
+        self._drop_history()
+        lp = np.empty(self.Nchains)
+        _lib.call("rmh_state_get", self._state, None, lp.ctypes.data)
+        self._host_thetas = _lib.as_f64(z["theta"])[None].copy()
+        self._host_logpost = lp[None].copy()
+        self._host_accept = np.zeros((0, self.Nchains), dtype=np.uint8)
+        self._kept = 1
+
     def current_state(self):
         """(theta, log_posterior) of the current state (sampler.py:56-60)."""
         th, lp = np.empty((self.Nchains, self.Npars)), np.empty(self.Nchains)

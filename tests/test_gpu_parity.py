@@ -623,3 +623,24 @@ def test_rccl_pooling_entry_points_single_rank(ra):
         np.testing.assert_allclose(mom[1 + d:].reshape(d, d), th.T @ th, rtol=1e-12, atol=1e-10)
     finally:
         _lib.call("rmh_comm_destroy")
+
+
+def test_checkpoint_restore_continues_bit_for_bit(ra, tmp_path):
+    from riemann_amd.models import benchmarks
+    from riemann_amd.proposals import AdaptScaleHMC
+    Ct = corr100()
+    m = benchmarks.benchmark_gauss100d_corr
+    th0 = np.random.default_rng(14).standard_normal((40, 100)) @ np.linalg.cholesky(Ct).T
+    a = ra.Sampler(m, AdaptScaleHMC(0.2, 3, m.grad_log_likelihood), th0, seed=9)
+    a.run(12)
+    ref_th, ref_lp = a.current_state()
+    b = ra.Sampler(m, AdaptScaleHMC(0.2, 3, m.grad_log_likelihood), th0, seed=9)
+    b.run(5)
+    b.checkpoint(str(tmp_path / "chains.npz"))
+    c = ra.Sampler(m, AdaptScaleHMC(0.2, 3, m.grad_log_likelihood), np.zeros((40, 100)), seed=12345)
+    c.restore(str(tmp_path / "chains.npz"))
+    c.run(7)
+    th, lp = c.current_state()
+    np.testing.assert_array_equal(th, ref_th)
+    np.testing.assert_array_equal(lp, ref_lp)
+    np.testing.assert_array_equal(c.proposal.scale, a.proposal.scale)

@@ -159,7 +159,16 @@ def main():
         import torch.distributed as dist
         local = local % max(torch.cuda.device_count(), 1)   # ranks that see one device each
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("RMH_BENCH_BACKEND", "nccl")   # "gloo": rehearsal without RCCL
+        if backend == "nccl":
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            except Exception as e:      # keep the measurement: the timed region has no collective
+                sys.stderr.write("bench: nccl process group failed (%r), using gloo\n" % (e,))
+                backend = "gloo"
+        if backend != "nccl":
+            dist.init_process_group(backend)
+        cdev = "cuda" if backend == "nccl" else None            # where collective buffers live
 
     import riemann_amd as ra
     from riemann_amd import _lib
@@ -191,7 +200,7 @@ def main():
     if dist is not None:    # first collectives build the RCCL communicator: keep that out of the timing
         import torch
         for _ in range(3):
-            dist.all_reduce(torch.zeros(1, dtype=torch.float64, device="cuda"), op=dist.ReduceOp.MAX)
+            dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=cdev), op=dist.ReduceOp.MAX)
             dist.barrier()
     barrier()
     kernel_ms, step_end = [], []
@@ -208,7 +217,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -218,8 +227,8 @@ def main():
         try:
             from riemann_amd.distributed import pool_samples, pooled_moments
             th, lp = s.current_state()
-            allth = pool_samples(th, world * N, device="cuda")      # RCCL all-gather over xGMI
-            mean, cov = pooled_moments(th, device="cuda")           # RCCL all-reduce
+            allth = pool_samples(th, world * N, device=cdev)        # RCCL all-gather over xGMI
+            mean, cov = pooled_moments(th, device=cdev)             # RCCL all-reduce
             pooled = {"allgather_bytes_per_rank": int(th.size * 8),
                       "pooled_chains": int(allth.shape[0]),
                       "pooled_mean_abs_max": float(np.abs(mean).max()),

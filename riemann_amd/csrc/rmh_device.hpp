@@ -168,6 +168,31 @@ RMH_DEV void logistic_gather(double eta, const double *tab, LogiGather &q)
     for (int k = 0; k < 10; ++k) q.c[k] = c[k];
 }
 
+// sigmoid only (gradient-only evaluations inside an HMC trajectory): half the table
+RMH_DEV double logistic_sigmoid(double eta, const double *tab)
+{
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    double a = __builtin_fabs(eta);
+    a = (a < 37.4999999) ? a : 37.4999999;
+    const double u = a * 4.0;
+    const int idx = (int)u;
+    const double t = fma_(2.0, u - __builtin_floor(u), -1.0);
+    const d2_t *c = static_cast<const d2_t *>(
+        __builtin_assume_aligned(tab + idx * (2 * kLogiNC) + kLogiNC, 16));
+    const d2_t s01 = c[0], s23 = c[1], s45 = c[2], s67 = c[3], s89 = c[4];
+    double sv = s89.y;
+    sv = fma_(sv, t, s89.x);
+    sv = fma_(sv, t, s67.y);
+    sv = fma_(sv, t, s67.x);
+    sv = fma_(sv, t, s45.y);
+    sv = fma_(sv, t, s45.x);
+    sv = fma_(sv, t, s23.y);
+    sv = fma_(sv, t, s23.x);
+    sv = fma_(sv, t, s01.y);
+    sv = fma_(sv, t, s01.x);
+    return (eta >= 0.0) ? 1.0 - sv : sv;
+}
+
 RMH_DEV void logistic_finish(double eta, const LogiGather &q, double &lse, double &sg)
 {
     const double t = q.t;

@@ -39,7 +39,7 @@ struct GaussModel {
     // logL = -0.5 (u.u + d log 2pi + logdetC), u = L^-1 (theta - mu)   gaussian.py:49-52
     // grad = -L^-T u                                                     gaussian.py:54-58
     // log_prior = 0 (gaussian.py:46-47); log_posterior guard model.py:49-55
-    template <bool GRAD>
+    template <bool GRAD, bool VALUE = true>
     static RMH_DEV void eval(const double *lds, const Args &m, bool grad_in_lds, int lane,
                              const double (&th)[S], double &lp, double (&grad)[S],
                              double (&parts)[2])
@@ -181,7 +181,7 @@ struct LogRegModel {
     // slower on MI355X: all eta / all link / all gradient phases (0.48 vs 0.51 of the
     // roof; 8 values in flight spill into AGPR traffic) and a hand pipeline that
     // parks the table gathers across the next MFMA block (0.48; 160 more live VGPRs).
-    template <bool GRAD>
+    template <bool GRAD, bool VALUE>
     static RMH_DEV void stage_compute(const double *cur, const double *ltab, const int (&eoff)[4],
                                       const int (&goff)[4], int g, int ks, const double (&th)[S],
                                       double &ll, double4_t (&G)[NT])
@@ -195,8 +195,12 @@ struct LogRegModel {
             for (int r = 0; r < 4; ++r) {
                 const double e = comp(eta, r), yv = yw[4 * r + g], wv = yw[16 + 4 * r + g];
                 double lse, sg;
-                logistic_terms(e, ltab, lse, sg);
-                ll += wv * (yv * e - lse);
+                if (VALUE) {
+                    logistic_terms(e, ltab, lse, sg);
+                    ll += wv * (yv * e - lse);
+                } else { // gradient-only evaluation: the log-likelihood value is not needed
+                    sg = logistic_sigmoid(e, ltab);
+                }
                 res[r] = wv * (yv - sg);
             }
             if (GRAD) grad_tile(img, goff, res, G);
@@ -205,7 +209,8 @@ struct LogRegModel {
 
     // logL = sum_i y_i eta_i - log(1 + exp(eta_i)),  eta = X beta
     // logP = -beta.beta / (2 tau2);  grad = X^T (y - sigmoid(eta)) - beta / tau2
-    template <bool GRAD>
+    // VALUE = false: gradient only (lp and parts are then meaningless)
+    template <bool GRAD, bool VALUE = true>
     static RMH_DEV void eval(double *lds, const Args &m, bool, int lane, const double (&th)[S],
                              double &lp, double (&grad)[S], double (&parts)[2])
     {
@@ -226,7 +231,7 @@ struct LogRegModel {
         for (int64_t c = 0; c < m.nchunks; ++c) {
             const double *cur = lds + (c & 1) * CHD;
             if (c + 1 < m.nchunks) stage(m, c + 1, lds + ((c + 1) & 1) * CHD);
-            stage_compute<GRAD>(cur, lds + 2 * CHD, eoff, goff, g, m.ks, th, ll, G);
+            stage_compute<GRAD, VALUE>(cur, lds + 2 * CHD, eoff, goff, g, m.ks, th, ll, G);
             __syncthreads();
         }
         ll = sum4(ll);

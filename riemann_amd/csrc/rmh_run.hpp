@@ -251,9 +251,11 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
             // (L2) so that the evaluation has the register file to itself
             T::store_state(ch.mom, ch.ld + 128, cm, g, p);
             asm volatile("" ::: "memory");
-            M::template eval<true>(lds, m, true, lane, q, lpp, gr, parts);
-            T::load_state(ch.mom, ch.ld + 128, cm, g, p);
             const bool last = step == pr.nsteps;
+            // the trajectory's inner gradients (hamiltonian.py:35) need no density value
+            if (last) M::template eval<true, true>(lds, m, true, lane, q, lpp, gr, parts);
+            else M::template eval<true, false>(lds, m, true, lane, q, lpp, gr, parts);
+            T::load_state(ch.mom, ch.ld + 128, cm, g, p);
             const double ek = last ? heps : eps; // :35 / :40
 #pragma unroll
             for (int s = 0; s < S; ++s) p[s] = p[s] + ek * gr[s];

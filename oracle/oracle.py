@@ -72,6 +72,11 @@ def lib():
     L.orc_run_adapt.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, vp, vp, vp, i32, vp]
     L.orc_run.restype = i32
     L.orc_run.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, vp, vp, vp, i32]
+    L.orc_rng_pt_stream.argtypes = [_u64p, i64, i32, i32, _f64p, _f64p, _f64p, _f64p]
+    L.orc_model_mixture.restype = vp
+    L.orc_model_mixture.argtypes = [_f64p, _f64p, _f64p, i32, i32, dbl]
+    L.orc_run_pt.restype = i32
+    L.orc_run_pt.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, _f64p, i32, dbl, vp, vp, vp]
     L.orc_max_threads.restype = i32
     _lib = L
     return L
@@ -96,6 +101,16 @@ def rng_stream(state, d, T):
     u = np.empty((T, N))
     lib().orc_rng_stream(state, N, d, T, xi, u)
     return xi, u
+
+
+def rng_pt_stream(state, d, T):
+    """Advance ``state`` (S,16) by T parallel-tempering sweeps; returns the selector
+    uniforms usel (T,S), swap uniforms vswap (T,S), normals xi (T,S,d), accept uniforms ua (T,S)."""
+    S = state.shape[0]
+    usel, vswp, ua = np.empty((T, S)), np.empty((T, S)), np.empty((T, S))
+    xi = np.empty((T, S, d))
+    lib().orc_rng_pt_stream(state, S, d, T, usel, vswp, xi, ua)
+    return usel, vswp, xi, ua
 
 
 def olog(x):
@@ -145,6 +160,20 @@ class Gaussian(_Model):
         mu = _c(np.atleast_1d(mu))
         Lc = _c(np.linalg.cholesky(np.atleast_2d(Cov)))
         super().__init__(lib().orc_model_gaussian(mu, Lc, len(mu)))
+
+
+class Mixture(_Model):
+    """benchmarks.MixtureDist of MultiGaussianDist components:
+    /root/reference/riemann/models/benchmarks.py:31-62.  components = [(weight, mu, C), ...]."""
+
+    def __init__(self, components):
+        w = np.array([c[0] for c in components], dtype=np.float64)
+        w = w / np.sum(w)                                  # benchmarks.py:40
+        mus = _c(np.array([np.atleast_1d(c[1]) for c in components], dtype=np.float64))
+        Ls = _c(np.array([np.linalg.cholesky(np.atleast_2d(c[2])) for c in components]))
+        logP0 = float(np.log(np.sum(w * np.exp(np.zeros(len(w))))))   # :54-62, component priors are 0
+        self.weights = w
+        super().__init__(lib().orc_model_mixture(_c(w), mus, Ls, len(w), mus.shape[1], logP0))
 
 
 class LogReg(_Model):
@@ -254,6 +283,35 @@ def run(model, proposal, theta, logpost, rng_state, T, history=True, nthreads=0,
     if rc != 0:
         raise ValueError("oracle: model and proposal dimensions differ")
     return ht, hl, acc
+
+
+def pt_slots(n_ensembles, K):
+    """Slot layout of parallel tempering (rmh_oracle.c section 5): returns (S, index)
+    with index[e, i] the slot of rung i of ensemble e."""
+    epw = 16 // K
+    e = np.arange(n_ensembles)
+    idx = ((e // epw) * 16 + (e % epw) * K)[:, None] + np.arange(K)[None, :]
+    S = -(-n_ensembles // epw) * 16
+    return S, idx
+
+
+def run_pt(model, proposal, theta, rng_state, T, betas, pswap, history=True):
+    """PTSampler.run over slots (/root/reference/riemann/samplers/ptsampler.py:84-127).
+    theta (S,d), rng_state (S,16) advanced in place.  Returns (hist_theta (T+1,S,d),
+    hist_logpost (T+1,S), code (T,S)), and the final logpost (S,)."""
+    S, d = theta.shape
+    betas = _c(betas)
+    logpost = np.zeros(S)
+    ht = np.zeros((T + 1, S, d)) if history else None
+    hl = np.zeros((T + 1, S)) if history else None
+    code = np.zeros((T, S), dtype=np.uint8)
+    rc = lib().orc_run_pt(model._h, proposal._h, S, theta, logpost, rng_state, T, betas,
+                          len(betas), float(pswap),
+                          ht.ctypes.data if history else None,
+                          hl.ctypes.data if history else None, code.ctypes.data)
+    if rc != 0:
+        raise ValueError("oracle: bad parallel-tempering arguments")
+    return ht, hl, code, logpost
 
 
 def max_threads():

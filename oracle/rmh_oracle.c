@@ -193,10 +193,26 @@ void orc_rng_stream(u64 *state, int64_t N, int d, int T, double *xi, double *u)
         }
 }
 
+/* the PT sweep's draws for S slots (section 5): usel, vswp, ua (T,S), xi (T,S,d) */
+void orc_rng_pt_stream(u64 *state, int64_t S, int d, int T, double *usel, double *vswp,
+                       double *xi, double *ua)
+{
+    for (int t = 0; t < T; t++)
+        for (int64_t c = 0; c < S; c++) {
+            u64 *st = state + 16 * c;
+            usel[(int64_t)t * S + c] = (double)(orc_next(st) >> 11) * ORC_2M53;
+            vswp[(int64_t)t * S + c] = (double)(orc_next(st + 4) >> 11) * ORC_2M53;
+            (void)orc_next(st + 8);
+            (void)orc_next(st + 12);
+            orc_rng_normals(st, d, xi + ((int64_t)t * S + c) * d);
+            ua[(int64_t)t * S + c] = orc_rng_uniform(st);
+        }
+}
+
 /* ------------------------------------------------------------------------- */
 /* 2. Models                                                                   */
 /* ------------------------------------------------------------------------- */
-enum { ORC_GAUSS = 1, ORC_LOGREG = 2, ORC_CHANGEPOINT = 3 };
+enum { ORC_GAUSS = 1, ORC_LOGREG = 2, ORC_CHANGEPOINT = 3, ORC_MIXTURE = 4 };
 
 typedef struct orc_model {
     int kind, d;
@@ -208,6 +224,10 @@ typedef struct orc_model {
     /* changepoint: models/changepoint.py:86-104 */
     int k; /* number of changepoints; pieces = k+1 */
     double *cx, *cy, xmin, xmax, lamb, alpha, beta;
+    /* mixture of Gaussians: models/benchmarks.py:31-60 */
+    int ncomp;
+    double *wts, logP0;
+    struct orc_model **comps;
 } orc_model;
 
 static double *orc_dup(const double *p, size_t n)
@@ -258,9 +278,30 @@ orc_model *orc_model_changepoint(const double *x, const double *y, int n, int k,
     return m;
 }
 
+/* benchmarks.MixtureDist(components) with MultiGaussianDist components,
+ * models/benchmarks.py:31-42.  `wts` are the NORMALISED weights (:40) and logP0 the
+ * constant log_prior, log(sum(wts * exp(0))) (:54-62), both formed by the caller
+ * with numpy exactly as the reference does. */
+orc_model *orc_model_mixture(const double *wts, const double *mu, const double *L, int ncomp,
+                             int d, double logP0)
+{
+    orc_model *m = (orc_model *)calloc(1, sizeof(*m));
+    m->kind = ORC_MIXTURE;
+    m->d = d;
+    m->ncomp = ncomp;
+    m->wts = orc_dup(wts, ncomp);
+    m->logP0 = logP0;
+    m->comps = (orc_model **)calloc(ncomp, sizeof(orc_model *));
+    for (int k = 0; k < ncomp; k++)
+        m->comps[k] = orc_model_gaussian(mu + (size_t)k * d, L + (size_t)k * d * d, d);
+    return m;
+}
+
 void orc_model_free(orc_model *m)
 {
     if (!m) return;
+    for (int k = 0; k < m->ncomp; k++) orc_model_free(m->comps[k]);
+    free(m->comps); free(m->wts);
     free(m->mu); free(m->L); free(m->X); free(m->y); free(m->cx); free(m->cy);
     free(m);
 }
@@ -296,6 +337,8 @@ static double orc_log_prior1(const orc_model *m, const double *th)
     switch (m->kind) {
     case ORC_GAUSS:
         return 0.0; /* gaussian.py:46-47 */
+    case ORC_MIXTURE:
+        return m->logP0; /* benchmarks.py:54-62: the components' log_prior is 0 */
     case ORC_LOGREG: {
         double s = 0;
         for (int j = 0; j < m->d; j++) s += th[j] * th[j];
@@ -335,6 +378,12 @@ static inline double orc_log1pexp(double e) /* log(1+exp(e)) */
 static double orc_log_lik1(const orc_model *m, const double *th, double *scratch)
 {
     switch (m->kind) {
+    case ORC_MIXTURE: { /* benchmarks.py:44-52: log(sum(w * exp(logL_k))), no log-sum-exp */
+        double acc = 0;
+        for (int k = 0; k < m->ncomp; k++)
+            acc += m->wts[k] * exp(orc_log_lik1(m->comps[k], th, scratch));
+        return log(acc);
+    }
     case ORC_GAUSS: { /* gaussian.py:49-52 */
         const int d = m->d;
         orc_gauss_u(m, th, scratch);
@@ -688,6 +737,120 @@ int orc_run_adapt(const orc_model *m, const orc_proposal *p, int64_t N, double *
         }
         free(work);
     }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* 5. PTSampler.run: samplers/ptsampler.py:42-127                               */
+/* ------------------------------------------------------------------------- */
+/*
+ * Replicas live in SLOTS grouped in tiles of 16 (one wavefront of the HIP kernel):
+ * with a ladder of K temperatures a tile holds EPW = 16/K ensembles, ensemble e of
+ * the tile in slots e*K .. e*K+K-1 (rung i = temperature betas[i]); slots >= EPW*K
+ * of a tile are idle and untouched.  theta (S,d), rng (S,16), S a multiple of 16.
+ *
+ * Each replica is a Sampler over TemperedModel(model, beta) (ptsampler.py:11-39:
+ * log_likelihood * beta, log_prior unchanged), so its log posterior is
+ * Model.log_posterior (model.py:43-55) of (logP, beta * logL).
+ *
+ * Stream use per sweep and slot (rmh-rng v2 extension): first ONE word from each
+ * of the slot's four sub-streams -- sub-stream 0's is the selector uniform `u` of
+ * ptsampler.py:103, sub-stream 1's the swap uniform of :119, the other two are
+ * unused -- then the within-chain draw of Sampler.sample (d normals, accept
+ * uniform), consumed whether or not the rung makes a within-chain move.
+ *
+ * Sweep, ptsampler.py:100-125: rungs in order; a rung already swapped is skipped
+ * (:104-106); rung i makes a within-chain MH step iff u > Pswap or i == K-1 (:107-109),
+ * else proposes to swap with rung i+1 (:110-125), accepted iff
+ *   U < min(1, exp(D)),  D = (logpost_ji + logpost_ij) - (logpost_ii + logpost_jj)
+ * restated as log(U) < min(0, D) with Python's min (NaN -> accept), the form the
+ * within-chain rule already has (sampler.py:83-84).
+ * Every replica appends exactly one state per sweep (sample() or _add_state()).
+ * code (T,S) uint8: bit 0 = the replica's state changed hands (accepted move or
+ * swap), bit 1 = the replica took part in a swap proposal.
+ * hist_theta ((T+1),S,d), hist_logpost ((T+1),S) as in orc_run; either may be NULL.
+ */
+static double orc_tempered(double lp, double ll, double beta)
+{
+    const double tl = ll * beta; /* ptsampler.py:35-36 */
+    if (isinf(lp) || isnan(lp) || isinf(tl) || isnan(tl)) return -INFINITY; /* model.py:49-52 */
+    return lp + tl;
+}
+
+int orc_run_pt(const orc_model *m, const orc_proposal *p, int64_t S, double *theta,
+               double *logpost, u64 *rng, int T, const double *betas, int K, double pswap,
+               double *hist_theta, double *hist_logpost, uint8_t *code)
+{
+    const int d = m->d;
+    if (p->d != d || p->kind != ORC_RW || K < 1 || K > 16 || (S & 15)) return -1;
+    const int EPW = 16 / K;
+    double *work = (double *)malloc(sizeof(double) * d * 6);
+    double *xi = work, *thp = work + d, *w2 = work + 2 * d;
+    double *lP = (double *)malloc(sizeof(double) * S), *lL = (double *)malloc(sizeof(double) * S);
+    for (int64_t c = 0; c < S; c++) { /* Sampler.__init__ of every rung, sampler.py:42 */
+        const int cl = (int)(c & 15);
+        lP[c] = orc_log_prior1(m, theta + c * d);
+        lL[c] = orc_log_lik1(m, theta + c * d, w2);
+        if (cl < EPW * K) logpost[c] = orc_tempered(lP[c], lL[c], betas[cl % K]);
+        if (hist_theta) memcpy(hist_theta + c * d, theta + c * d, sizeof(double) * d);
+        if (hist_logpost) hist_logpost[c] = logpost[c];
+    }
+    for (int t = 0; t < T; t++) {
+        for (int64_t e0 = 0; e0 < S; e0 += 16)
+            for (int e = 0; e < EPW; e++) {
+                const int64_t base = e0 + (int64_t)e * K;
+                int swapped_next = 0;
+                for (int i = 0; i < K; i++) {
+                    const int64_t c = base + i;
+                    u64 *st = rng + 16 * c;
+                    const double usel = (double)(orc_next(st) >> 11) * ORC_2M53;
+                    const double vswp = (double)(orc_next(st + 4) >> 11) * ORC_2M53;
+                    (void)orc_next(st + 8);
+                    (void)orc_next(st + 12);
+                    orc_rng_normals(st, d, xi);
+                    const double ua = orc_rng_uniform(st);
+                    uint8_t cd = 0;
+                    if (swapped_next) { /* :104-106; its state was appended by rung i-1 */
+                        swapped_next = 0;
+                        continue;
+                    }
+                    double *th = theta + c * d;
+                    if (usel > pswap || i == K - 1) { /* within-chain step, Sampler.sample */
+                        orc_propose1(p, m, th, xi, thp, w2, 1.0);
+                        const double pP = orc_log_prior1(m, thp), pL = orc_log_lik1(m, thp, w2);
+                        const double lpp = orc_tempered(pP, pL, betas[i]);
+                        const double delta = lpp - logpost[c] - 0.0;
+                        const double mh = (delta < 0) ? delta : 0.0;
+                        if (orc_log(ua) < mh) {
+                            memcpy(th, thp, sizeof(double) * d);
+                            logpost[c] = lpp; lP[c] = pP; lL[c] = pL;
+                            cd = 1;
+                        }
+                        if (code) code[(int64_t)t * S + c] = cd;
+                    } else { /* swap proposal with the next rung, :110-125 */
+                        const int64_t j = c + 1;
+                        const double lij = orc_tempered(lP[j], lL[j], betas[i]);     /* model_i(theta_j) */
+                        const double lji = orc_tempered(lP[c], lL[c], betas[i + 1]); /* model_j(theta_i) */
+                        const double delta = (lji + lij) - (logpost[c] + logpost[j]);
+                        const double mh = (delta < 0) ? delta : 0.0;
+                        cd = 2;
+                        if (orc_log(vswp) < mh) {
+                            double *tj = theta + j * d;
+                            for (int q = 0; q < d; q++) { const double x = th[q]; th[q] = tj[q]; tj[q] = x; }
+                            double x = lP[c]; lP[c] = lP[j]; lP[j] = x;
+                            x = lL[c]; lL[c] = lL[j]; lL[j] = x;
+                            logpost[c] = lij; logpost[j] = lji;
+                            cd = 3;
+                        }
+                        if (code) { code[(int64_t)t * S + c] = cd; code[(int64_t)t * S + j] = cd; }
+                        swapped_next = 1;
+                    }
+                }
+            }
+        if (hist_theta) memcpy(hist_theta + (int64_t)(t + 1) * S * d, theta, sizeof(double) * S * d);
+        if (hist_logpost) memcpy(hist_logpost + (int64_t)(t + 1) * S, logpost, sizeof(double) * S);
+    }
+    free(work); free(lP); free(lL);
     return 0;
 }
 

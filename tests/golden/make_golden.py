@@ -407,7 +407,146 @@ def g10_pcn():
          rho=np.float64(0.8), **r)
 
 
+def g11_mixture():
+    """benchmarks.MixtureDist (models/benchmarks.py:31-85): density values and a
+    random-walk run on the two mixture benchmarks."""
+    rng = np.random.default_rng(11)
+    out = {}
+    for name, m, d in (("mix1d", rbench.benchmark_gauss1d_mix2, 1),
+                       ("mix2d", rbench.benchmark_gauss2d_mix2_cross, 2)):
+        pts = np.concatenate([rng.standard_normal((40, d)) * 4.0,
+                              rng.standard_normal((8, d)) * 60.0])   # far tail: exp underflows -> -inf
+        with np.errstate(divide="ignore"):
+            out[name + "_theta"] = pts
+            out[name + "_logL"] = np.array([m.log_likelihood(t) for t in pts])
+            out[name + "_logP"] = np.array([m.log_prior(t) for t in pts])
+            out[name + "_logpost"] = np.array([m.log_posterior(t) for t in pts])
+        out[name + "_weights"] = np.array(m._mixweights)
+    save("g11_mixture_values", **out)
+    m = rbench.benchmark_gauss2d_mix2_cross
+    th0 = rng.standard_normal((4, 2))
+    r = run_reference(m, lambda: MetropolisRandomWalk(1.5 * np.eye(2)), th0, seed=110, T=96)
+    save("g11_mixture_rw", Cprop=1.5 * np.eye(2), **r)
+    m1 = rbench.benchmark_gauss1d_mix2
+    r = run_reference(m1, lambda: MetropolisRandomWalk(np.array([[9.0]])), np.array([[5.0], [-5.0], [0.0], [1.0]]),
+                      seed=111, T=96)
+    save("g11_mixture1d_rw", Cprop=np.array([[9.0]]), **r)
+
+
+class PTReplay:
+    """Feeds the draws of one parallel-tempering ensemble to the reference's PTSampler.
+    The call sites tell the draws apart: the selector `u` (ptsampler.py:103) opens a
+    rung, the swap uniform is the other draw made from PTSampler.sample (:119), the
+    accept uniform comes from Sampler.sample (sampler.py:84), the normals from the
+    proposal (randomwalk.py:25)."""
+
+    def __init__(self, usel, vswp, xi, ua):
+        self.usel, self.vswp, self.xi, self.ua = usel, vswp, xi, ua   # (T,K), (T,K), (T,K,d), (T,K)
+        self.t, self.rung = -1, -1
+        self.swaps = np.zeros(usel.shape, dtype=np.uint8)
+
+    def next_sweep(self):
+        self.t += 1
+        self.rung = -1
+
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        v = self.xi[self.t, self.rung]
+        shape = (size,) if np.isscalar(size) else tuple(size)
+        assert v.shape == shape, (v.shape, shape)
+        return v.copy()
+
+    def uniform(self, low=0.0, high=1.0, size=None):
+        import linecache
+        assert size is None
+        fr = sys._getframe(1)
+        fn, line = fr.f_code.co_filename, linecache.getline(fr.f_code.co_filename, fr.f_lineno)
+        if fn.endswith("ptsampler.py"):
+            if line.strip().startswith("u = "):
+                self.rung += 1
+                return float(self.usel[self.t, self.rung])
+            assert "mhratio" in line, line
+            self.swaps[self.t, self.rung] = 1
+            return float(self.vswp[self.t, self.rung])
+        assert fn.endswith("sampler.py"), fn
+        return float(self.ua[self.t, self.rung])
+
+
+def run_reference_pt(model, make_proposal, theta0, seed, T, pswap):
+    """The reference's PTSampler (default ladder betas = 0.5**arange(5)) for every
+    ensemble, on the slot layout of oracle/rmh_oracle.c section 5."""
+    import contextlib
+    import io
+    from riemann.samplers.ptsampler import PTSampler
+    theta0 = np.atleast_2d(np.asarray(theta0, dtype=np.float64))
+    Ne, d = theta0.shape
+    K = 5
+    S, idx = orc.pt_slots(Ne, K)
+    st = orc.rng_seed(seed, S)
+    usel, vswp, xi, ua = orc.rng_pt_stream(st, d, T)
+    thetas = np.zeros((T + 1, S, d))
+    logpost = np.zeros((T + 1, S))
+    within_acc = np.zeros((T, S), dtype=np.uint8)
+    swap_prop = np.zeros((T, S), dtype=np.uint8)
+    swap_acc = np.zeros((T, S), dtype=np.int8)      # -1: cannot be told (identical objects)
+    real_normal, real_uniform = np.random.normal, np.random.uniform
+    try:
+        for e in range(Ne):
+            sl = idx[e]
+            rp = PTReplay(usel[:, sl], vswp[:, sl], xi[:, sl], ua[:, sl])
+            np.random.normal, np.random.uniform = rp.normal, rp.uniform
+            with contextlib.redirect_stdout(io.StringIO()):
+                pt = PTSampler(model, make_proposal(), theta0[e].copy(), Pswap=pswap)
+            betas = np.array(pt.betas, dtype=np.float64)
+            for i, smp in enumerate(pt.samplers):
+                thetas[0, sl[i]] = smp._chain_thetas[-1]
+                logpost[0, sl[i]] = smp._chain_logpost[-1]
+            for t in range(T):
+                before = [smp._chain_thetas[-1] for smp in pt.samplers]
+                rp.next_sweep()
+                pt.sample()
+                assert rp.rung == K - 1
+                for i, smp in enumerate(pt.samplers):
+                    assert len(smp._chain_thetas) == t + 2          # one state per sweep and rung
+                    thetas[t + 1, sl[i]] = smp._chain_thetas[-1]
+                    logpost[t + 1, sl[i]] = smp._chain_logpost[-1]
+                for i in range(K):
+                    if rp.swaps[t, i]:
+                        swap_prop[t, sl[i]] = swap_prop[t, sl[i + 1]] = 1
+                        if before[i] is before[i + 1]:
+                            ok = -1
+                        else:
+                            ok = int(pt.samplers[i]._chain_thetas[-1] is before[i + 1])
+                        swap_acc[t, sl[i]] = swap_acc[t, sl[i + 1]] = ok
+                for i, smp in enumerate(pt.samplers):
+                    if not swap_prop[t, sl[i]]:
+                        within_acc[t, sl[i]] = smp._chain_thetas[-1] is not before[i]
+    finally:
+        np.random.normal, np.random.uniform = real_normal, real_uniform
+    return dict(seed=np.uint64(seed), theta0=theta0, betas=betas, pswap=np.float64(pswap),
+                slots=idx, thetas=thetas, logpost=logpost, within_acc=within_acc,
+                swap_prop=swap_prop, swap_acc=swap_acc, usel=usel, vswp=vswp, ua=ua)
+
+
+def g12_pt():
+    """PTSampler (samplers/ptsampler.py:42-127), default ladder, on a Gaussian and on the
+    crossed 2-d mixture; Pswap large enough that swaps are frequent."""
+    rng = np.random.default_rng(12)
+    m = rbench.benchmark_gauss2d_corr
+    r = run_reference_pt(m, lambda: MetropolisRandomWalk(0.5 * np.eye(2)),
+                         rng.standard_normal((4, 2)), seed=120, T=96, pswap=0.3)
+    save("g12_pt_gauss2d", mu=np.zeros(2), C=0.1 * np.eye(2) + 0.9 * np.ones((2, 2)),
+         Cprop=0.5 * np.eye(2), **r)
+    mx = rbench.benchmark_gauss2d_mix2_cross
+    r = run_reference_pt(mx, lambda: MetropolisRandomWalk(1.5 * np.eye(2)),
+                         rng.standard_normal((3, 2)) * 2.0, seed=121, T=96, pswap=0.1)
+    save("g12_pt_mix2d", Cprop=1.5 * np.eye(2), **r)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:          # regenerate selected fixtures: make_golden.py g11_mixture g12_pt
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g0_rng()
     g1_gauss2d_rw()
     g2_gauss100d_rw()
@@ -419,3 +558,5 @@ if __name__ == "__main__":
     g8_adapt_scale()
     g9_hmc_mass()
     g10_pcn()
+    g11_mixture()
+    g12_pt()

@@ -271,3 +271,58 @@ def test_g10_pcn():
                          orc.PCN(0.7 * Ct + 0.3 * np.eye(100), float(z["rho"]))))
     z = load("g10_pcn_gauss2d")
     check_run(z, *replay(z, orc.Gaussian(z["mu"], z["C"]), orc.PCN(z["Cprop"], float(z["rho"]))))
+
+
+MIX1D = [(0.3, [-5.0], [[1.0]]), (0.7, [5.0], [[1.0]])]                       # benchmarks.py:75-78
+MIX2D = [(0.3, [0.0, 0.0], [[1.0, 0.9], [0.9, 1.0]]),                         # benchmarks.py:81-84
+         (0.7, [0.0, 0.0], [[1.0, -0.9], [-0.9, 1.0]])]
+
+
+def test_g11_mixture_values_and_random_walk():
+    z = load("g11_mixture_values")
+    for name, comps in (("mix1d", MIX1D), ("mix2d", MIX2D)):
+        m = orc.Mixture(comps)
+        np.testing.assert_array_equal(m.weights, z[name + "_weights"])
+        th = z[name + "_theta"]
+        for fn, key in ((m.log_likelihood, "_logL"), (m.log_prior, "_logP"), (m.log_posterior, "_logpost")):
+            got, ref = fn(th), z[name + key]
+            assert np.array_equal(np.isinf(got), np.isinf(ref))
+            fin = np.isfinite(ref)
+            np.testing.assert_allclose(got[fin], ref[fin], rtol=RTOL, atol=1e-15)
+        assert np.isinf(z[name + "_logpost"]).any()    # the underflow -> -inf case is in the fixture
+    z = load("g11_mixture_rw")
+    check_run(z, *replay(z, orc.Mixture(MIX2D), orc.RandomWalk(z["Cprop"])))
+    z = load("g11_mixture1d_rw")
+    check_run(z, *replay(z, orc.Mixture(MIX1D), orc.RandomWalk(z["Cprop"])))
+
+
+def pt_replay(z, model):
+    """The oracle's PT run on the fixture's slot layout: (hist_theta, hist_logpost, code)."""
+    idx = z["slots"]
+    Ne, K = idx.shape
+    S, idx2 = orc.pt_slots(Ne, K)
+    np.testing.assert_array_equal(idx, idx2)
+    th = np.zeros((S, z["theta0"].shape[1]))
+    th[idx] = z["theta0"][:, None, :]            # PTSampler gives every rung the same theta0 (:82)
+    st = orc.rng_seed(int(z["seed"]), S)
+    T = z["swap_prop"].shape[0]
+    ht, hl, code, _ = orc.run_pt(model, orc.RandomWalk(z["Cprop"]), th, st, T, z["betas"], float(z["pswap"]))
+    return ht, hl, code, idx.ravel()
+
+
+def check_pt(z, ht, hl, code, valid):
+    np.testing.assert_array_equal(code[:, valid] >> 1, z["swap_prop"][:, valid])
+    known = z["swap_acc"][:, valid] >= 0
+    sw = z["swap_prop"][:, valid] == 1
+    np.testing.assert_array_equal((code[:, valid] & 1)[sw & known], z["swap_acc"][:, valid][sw & known])
+    np.testing.assert_array_equal((code[:, valid] & 1)[~sw], z["within_acc"][:, valid][~sw])
+    np.testing.assert_allclose(ht[:, valid], z["thetas"][:, valid], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(hl[:, valid], z["logpost"][:, valid], rtol=RTOL)
+    assert sw.sum() > 20 and (z["swap_acc"][:, valid] == 1).sum() > 5
+
+
+def test_g12_parallel_tempering():
+    z = load("g12_pt_gauss2d")
+    check_pt(z, *pt_replay(z, orc.Gaussian(z["mu"], z["C"])))
+    z = load("g12_pt_mix2d")
+    check_pt(z, *pt_replay(z, orc.Mixture(MIX2D)))

@@ -68,6 +68,12 @@ int rmh_model_logreg_create(const double *X, const double *y, int64_t n, int d,
 int rmh_model_changepoint_create(const double *x, const double *y, int n, int k,
                                  double xmin, double xmax, double lamb,
                                  double alpha, double beta, rmh_model_t *out);
+/* benchmarks.MixtureDist(components) with MultiGaussianDist components,
+ * models/benchmarks.py:31-62 (targets benchmark_gauss1d_mix2, benchmark_gauss2d_mix2_cross,
+ * :75-85).  weights (ncomp) NORMALISED as at :40, mu (ncomp,d), L (ncomp,d,d) the components'
+ * Cholesky factors, log_prior the constant log(sum(w exp(0))) of :54-62.  No gradient. */
+int rmh_model_mixture_create(const double *weights, const double *mu, const double *L, int ncomp,
+                             int d, double log_prior, rmh_model_t *out);
 int rmh_model_dim(rmh_model_t m, int *d);
 int rmh_model_free(rmh_model_t m);
 
@@ -144,6 +150,23 @@ int rmh_history_free(rmh_history_t h);
  * current state afterwards is the LAST KEPT entry. */
 int rmh_run(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t nburn,
             int64_t nthin, rmh_history_t h);
+
+/* ---- PTSampler.run: samplers/ptsampler.py:42-127 ----------------------------
+ * Parallel tempering over a ladder betas[0..K-1] (1 <= K <= 16).  The chains of `s`
+ * are SLOTS grouped in tiles of 16 (one wavefront): a tile holds 16/K ensembles,
+ * ensemble e of the tile in slots e*K .. e*K+K-1, rung i sampling
+ * TemperedModel(model, betas[i]) (:11-39); slots >= K*(16/K) of a tile are idle.
+ * One sweep = PTSampler.sample (:92-127): per rung one selector uniform, then either
+ * the within-chain MH step of Sampler.sample or a swap proposal with the next rung;
+ * a swap exchanges the two replicas' registers inside the wavefront.  Every replica
+ * records one state per sweep; T, nburn, nthin, h as in rmh_run (the reference
+ * ignores Nburn/Nthin here, :84; pass 0, 1 for its behaviour).  Accept codes in the
+ * history: bit 0 = the replica's state changed (accepted move or swap), bit 1 = the
+ * replica took part in a swap proposal.  The state's log posteriors are the TEMPERED
+ * ones.  Within-chain proposal: MetropolisRandomWalk; models: Gaussian, mixture.
+ * Stream use per sweep: DESIGN.md, "Parallel tempering". */
+int rmh_run_pt(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, const double *betas, int K,
+               double pswap, int64_t T, int64_t nburn, int64_t nthin, rmh_history_t h);
 
 /* ---- pooling the chains of several GPUs (no reference counterpart:
  *      riemann/README.md:21-23 only states the aspiration) ---------------------

@@ -32,6 +32,7 @@ SIGNATURES = {
     "rmh_model_gaussian_create": [_f64, _f64, _int, _pvp],
     "rmh_model_logreg_create": [_f64, _f64, _i64, _int, _dbl, _pvp],
     "rmh_model_changepoint_create": [_f64, _f64, _int, _int, _dbl, _dbl, _dbl, _dbl, _dbl, _pvp],
+    "rmh_model_mixture_create": [_f64, _f64, _f64, _int, _int, _dbl, _pvp],
     "rmh_model_dim": [_vp, C.POINTER(_int)],
     "rmh_model_free": [_vp],
     "rmh_log_prior": [_vp, _f64, _i64, _f64],
@@ -63,6 +64,7 @@ SIGNATURES = {
     "rmh_history_device_ptrs": [_vp, _pvp, _pvp, _pvp, C.POINTER(_i64)],
     "rmh_history_free": [_vp],
     "rmh_run": [_vp, _vp, _vp, _i64, _i64, _i64, _vp],
+    "rmh_run_pt": [_vp, _vp, _vp, _f64, _int, _dbl, _i64, _i64, _i64, _vp],
     "rmh_comm_unique_id": [_u8],
     "rmh_comm_init": [_u8, _int, _int],
     "rmh_comm_destroy": [],

@@ -126,6 +126,9 @@ struct rmh_model {
     int k = 0;
     double *d_xy = nullptr;
     CpArgs ca{};
+    // mixture of gaussians
+    double *d_mixW = nullptr, *d_mixmu = nullptr, *d_mixc = nullptr, *d_mixw = nullptr;
+    MixArgs ma{};
 };
 
 struct rmh_proposal {
@@ -144,6 +147,7 @@ struct rmh_state {
     int d = 0, dp = 0, ks = 0, NT = 0;
     double *theta = nullptr, *grad = nullptr, *mom = nullptr, *logpost = nullptr;
     double *adapt = nullptr; // 3 x ld: Nsamples, Naccepts, scale (AdaptScaleProposal)
+    double *pt_beta = nullptr; // ld: inverse temperature of every slot (rmh_run_pt)
     uint64_t *rng = nullptr;
     bool valid = false, grad_valid = false;
 };
@@ -216,6 +220,11 @@ int eval_states(rmh_model *m, const ChainArgs &c, bool want_grad, double *lp, do
         break;
     case kLogReg:
         e = launch_logreg_eval(m->NT, m->la, c, want_grad, lp, grad, lprior, llik, g_stream);
+        break;
+    case kMixture:
+        if (want_grad)
+            return fail(RMH_ERR_PARAM, "MixtureDist has no gradient (riemann/models/benchmarks.py:31-62)");
+        e = launch_mix_eval(m->NT, m->ma, c, lp, lprior, llik, g_stream);
         break;
     case kChangepoint:
         if (want_grad)
@@ -439,6 +448,56 @@ int rmh_model_gaussian_create(const double *mu, const double *L, int d, rmh_mode
     return RMH_OK;
 }
 
+int rmh_model_mixture_create(const double *weights, const double *mu, const double *L, int ncomp,
+                             int d, double log_prior, rmh_model_t *out)
+{
+    RMH_NEED_INIT();
+    if (!weights || !mu || !L || !out || ncomp < 1 || d < 1) return fail(RMH_ERR_PARAM, "mixture: bad argument");
+    const int NT = nt_for_dim(d);
+    if (NT < 0) return fail(RMH_ERR_PARAM, "mixture: d > 112 is not supported by the MFMA tile yet");
+    std::vector<double> imgs, mus((size_t)ncomp * 16 * NT, 0.0), cst(ncomp);
+    for (int k = 0; k < ncomp; ++k) {
+        const double *Lk = L + (size_t)k * d * d;
+        if (!lower_ok(Lk, d))
+            return fail(RMH_ERR_PARAM, "mixture: every L must be a lower-triangular Cholesky factor");
+        std::vector<double> W((size_t)d * d, 0.0);
+        for (int col = 0; col < d; ++col)
+            for (int i = col; i < d; ++i) {
+                double acc = (i == col) ? 1.0 : 0.0;
+                for (int j = col; j < i; ++j) acc -= Lk[i * d + j] * W[j * d + col];
+                W[i * d + col] = acc / Lk[i * d + i];
+            }
+        std::vector<double> lo = pack_lower(W.data(), d, NT, 1.0);
+        imgs.insert(imgs.end(), lo.begin(), lo.end());
+        for (int i = 0; i < d; ++i) mus[(size_t)k * 16 * NT + i] = mu[(size_t)k * d + i];
+        double slog = 0.0;
+        for (int i = 0; i < d; ++i) slog += std::log(Lk[i * d + i]);
+        cst[k] = 2 * slog;                     // gaussian.py:43
+    }
+    rmh_model *m = new rmh_model;
+    m->kind = kMixture;
+    m->d = d;
+    m->NT = NT;
+    int rc;
+    if ((rc = upload(&m->d_mixW, imgs.data(), imgs.size())) ||
+        (rc = upload(&m->d_mixmu, mus.data(), mus.size())) ||
+        (rc = upload(&m->d_mixc, cst.data(), cst.size())) ||
+        (rc = upload(&m->d_mixw, weights, (size_t)ncomp))) {
+        rmh_model_free(m);
+        return rc;
+    }
+    m->ma.Wtiles = m->d_mixW;
+    m->ma.mu_pad = m->d_mixmu;
+    m->ma.cst = m->d_mixc;
+    m->ma.wts = m->d_mixw;
+    m->ma.ncomp = ncomp;
+    m->ma.ks = (d + 3) / 4;
+    m->ma.dlog2pi = d * std::log(2 * M_PI);    // gaussian.py:52
+    m->ma.logP0 = log_prior;
+    *out = m;
+    return RMH_OK;
+}
+
 int rmh_model_logreg_create(const double *X, const double *y, int64_t n, int d, double tau2,
                             rmh_model_t *out)
 {
@@ -537,6 +596,10 @@ int rmh_model_free(rmh_model_t m)
     (void)hipFree(m->d_mu);
     (void)hipFree(m->d_X);
     (void)hipFree(m->d_xy);
+    (void)hipFree(m->d_mixW);
+    (void)hipFree(m->d_mixmu);
+    (void)hipFree(m->d_mixc);
+    (void)hipFree(m->d_mixw);
     delete m;
     return RMH_OK;
 }
@@ -892,6 +955,7 @@ int rmh_state_free(rmh_state_t s)
     (void)hipFree(s->grad);
     (void)hipFree(s->mom);
     (void)hipFree(s->adapt);
+    (void)hipFree(s->pt_beta);
     (void)hipFree(s->logpost);
     (void)hipFree(s->rng);
     delete s;
@@ -1004,8 +1068,10 @@ int rmh_history_free(rmh_history_t h)
 }
 
 // ---------------------------------------------------------------------- run
-int rmh_run(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t nburn,
-            int64_t nthin, rmh_history_t h)
+} // extern "C"
+
+static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t nburn,
+                    int64_t nthin, rmh_history_t h, const double *betas, int K, double pswap)
 {
     RMH_NEED_INIT();
     if (!m || !p || !s) return fail(RMH_ERR_PARAM, "run: null handle");
@@ -1042,9 +1108,28 @@ int rmh_run(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t n
     r.h_theta = h ? h->thetas : nullptr;
     r.h_logpost = h ? h->logpost : nullptr;
     r.h_accept = h ? h->accept : nullptr;
+    if (K > 0) { // parallel tempering: the slots' inverse temperatures
+        if (p->kind != kRW || adapt)
+            return fail(RMH_ERR_PARAM, "run_pt: built for MetropolisRandomWalk within-chain moves only");
+        if (m->kind != kGauss && m->kind != kMixture)
+            return fail(RMH_ERR_PARAM, "run_pt: built for the Gaussian and mixture models only");
+        std::vector<double> b((size_t)s->ld, 1.0);
+        const int used = (16 / K) * K;
+        for (int64_t c0 = 0; c0 < s->ld; ++c0)
+            if ((c0 & 15) < used) b[c0] = betas[(c0 & 15) % K];
+        if (!s->pt_beta && (rc = dev_alloc(&s->pt_beta, (size_t)s->ld))) return rc;
+        RMH_HIP(hipMemcpy(s->pt_beta, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice));
+        r.pt_beta = s->pt_beta;
+        r.pt_K = K;
+        r.pt_pswap = pswap;
+    }
     RMH_HIP(hipEventRecord(g_ev0, g_stream));
     hipError_t e = hipSuccess;
-    if (p->kind == kPCN) {
+    if (K > 0) {
+        RwArgs ra{p->d_Ltiles, nullptr, 0.0};
+        e = m->kind == kGauss ? launch_gauss_pt(m->NT, m->ga, ra, c, r, g_stream)
+                              : launch_mix_rw(m->NT, m->ma, ra, c, r, g_stream);
+    } else if (p->kind == kPCN) {
         RwArgs ra{p->d_Ltiles, p->d_V, p->rho};
         if (m->kind != kGauss) return fail(RMH_ERR_PARAM, "run: pCN is built for the Gaussian model only");
         if (adapt) return fail(RMH_ERR_PARAM, "run: AdaptScalepCN is not built");
@@ -1053,9 +1138,12 @@ int rmh_run(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t n
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
         if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
         else if (m->kind == kChangepoint) e = launch_cp_rw(m->k, m->ca, ra, c, r, g_stream);
+        else if (m->kind == kMixture && !adapt) e = launch_mix_rw(m->NT, m->ma, ra, c, r, g_stream);
+        else if (m->kind == kMixture) return fail(RMH_ERR_PARAM, "run: scale adaptation is not built for the mixture model");
         else return fail(RMH_ERR_PARAM, "run: random walk on the logistic model is not built yet");
     } else {
         HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT};
+        if (m->kind == kMixture) return fail(RMH_ERR_PARAM, "hmc: MixtureDist has no gradient");
         if (m->kind == kGauss) e = launch_gauss_hmc(m->NT, m->ga, ha, c, r, adapt, g_stream);
         else e = launch_logreg_hmc(m->NT, m->la, ha, c, r, adapt, g_stream);
     }
@@ -1078,6 +1166,26 @@ int rmh_run(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t n
         }
     }
     return RMH_OK;
+}
+
+extern "C" {
+
+int rmh_run(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t nburn,
+            int64_t nthin, rmh_history_t h)
+{
+    return run_impl(m, p, s, T, nburn, nthin, h, nullptr, 0, 0.0);
+}
+
+int rmh_run_pt(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, const double *betas, int K,
+               double pswap, int64_t T, int64_t nburn, int64_t nthin, rmh_history_t h)
+{
+    if (!betas || K < 1 || K > 16) return fail(RMH_ERR_PARAM, "run_pt: need 1 <= K <= 16 temperatures");
+    for (int i = 0; i < K; ++i)
+        if (!(betas[i] >= 0.0 && betas[i] <= 1.0)) // TemperedModel.__init__, ptsampler.py:26-27
+            return fail(RMH_ERR_PARAM, "beta must be a number between 0 and 1");
+    if (!(pswap > 0.0 && pswap < 1.0))             // PTSampler.__init__, ptsampler.py:72-73
+        return fail(RMH_ERR_PARAM, "Pswap must be a number between 0 and 1");
+    return run_impl(m, p, s, T, nburn, nthin, h, betas, K, pswap);
 }
 
 // --------------------------------------------------------------- test hooks

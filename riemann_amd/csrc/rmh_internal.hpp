@@ -6,7 +6,7 @@
 
 namespace rmh {
 
-enum ModelKind { kGauss = 1, kLogReg = 2, kChangepoint = 3 };
+enum ModelKind { kGauss = 1, kLogReg = 2, kChangepoint = 3, kMixture = 4 };
 enum ProposalKind { kRW = 1, kHMC = 2, kPCN = 3 };
 
 // ---- device-side argument blocks (passed by value to the kernels) ----------
@@ -17,6 +17,18 @@ struct GaussArgs {
     double dlog2pi;        // d*log(2 pi)
     double logdetC;
     int ks;                // ceil(d/4): k-steps that carry data
+};
+
+// benchmarks.MixtureDist of MultiGaussianDist components (models/benchmarks.py:31-62)
+struct MixArgs {
+    const double *Wtiles;  // ncomp lower-triangular tile images of W_k = L_k^-1 (global memory, L2)
+    const double *mu_pad;  // ncomp x 16*NT doubles
+    const double *cst;     // ncomp: logdetC_k
+    const double *wts;     // ncomp normalised weights
+    int ncomp;
+    int ks;
+    double dlog2pi;
+    double logP0;          // the constant log_prior, log(sum(w exp(0)))
 };
 
 struct LogRegArgs {
@@ -63,6 +75,10 @@ struct RunArgs {
     double *h_theta;    // (entries, 4*ks, ld) or null
     double *h_logpost;  // (entries, ld)
     uint8_t *h_accept;  // (T, ld) or null
+    // parallel tempering (PTSampler, samplers/ptsampler.py:42-127); pt_K = 0: off
+    const double *pt_beta; // (ld) inverse temperature of every slot
+    int pt_K;              // ladder size: a 16-slot tile holds 16/K ensembles, rung-minor
+    double pt_pswap;
 };
 
 struct RwArgs {
@@ -91,6 +107,13 @@ hipError_t launch_gauss_eval(int NT, const GaussArgs &m, const ChainArgs &c, int
 // `adapt`: run the AdaptScale* variant (c.adapt / c.adapt_target set, tile image unscaled)
 hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                            const RunArgs &r, bool adapt, hipStream_t st);
+hipError_t launch_gauss_pt(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
+                           const RunArgs &r, hipStream_t st);
+hipError_t launch_mix_eval(int NT, const MixArgs &m, const ChainArgs &c, double *lp_out,
+                           double *lprior_out, double *llik_out, hipStream_t st);
+// r.pt_K > 0 selects the parallel-tempering variant
+hipError_t launch_mix_rw(int NT, const MixArgs &m, const RwArgs &p, const ChainArgs &c,
+                         const RunArgs &r, hipStream_t st);
 hipError_t launch_gauss_pcn(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                             const RunArgs &r, hipStream_t st);
 // p.chM != null selects the mass-matrix variant

@@ -61,6 +61,40 @@ hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const Ch
     })
 }
 
+// parallel tempering over a Gaussian target: one wave per SIMD (register budget)
+hipError_t launch_gauss_pt(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
+                           const RunArgs &r, hipStream_t st)
+{
+    RMH_NT_DISPATCH(NT, {
+        using M = GaussModel<kNT>;
+        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false) + kIcdfDoubles);
+        return launch(k_run_rw<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
+    })
+}
+
+// ------------------------------------------------------ mixture of Gaussians
+hipError_t launch_mix_eval(int NT, const MixArgs &m, const ChainArgs &c, double *lp_out,
+                           double *lprior_out, double *llik_out, hipStream_t st)
+{
+    RMH_NT_DISPATCH(NT, {
+        using M = MixModel<kNT>;
+        return launch(k_eval<M, false, 4>, c.nblocks, 4, 0, st, m, c, lp_out, (double *)nullptr,
+                      lprior_out, llik_out);
+    })
+}
+
+hipError_t launch_mix_rw(int NT, const MixArgs &m, const RwArgs &p, const ChainArgs &c,
+                         const RunArgs &r, hipStream_t st)
+{
+    RMH_NT_DISPATCH(NT, {
+        using M = MixModel<kNT>;
+        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + kIcdfDoubles);
+        if (r.pt_K > 0)
+            return launch(k_run_rw<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
+        return launch(k_run_rw<M, 4, false, false, false>, c.nblocks, 4, lds, st, m, p, c, r);
+    })
+}
+
 hipError_t launch_gauss_pcn(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                             const RunArgs &r, hipStream_t st)
 {

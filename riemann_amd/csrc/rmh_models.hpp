@@ -100,6 +100,56 @@ struct GaussModel {
     }
 };
 
+// ------------------------------------------------- mixture of Gaussians
+// benchmarks.MixtureDist with MultiGaussianDist components (models/benchmarks.py:31-62):
+//   log_likelihood = log(sum_k w_k exp(logL_k))   (:44-52, no log-sum-exp: underflow -> -inf)
+//   log_prior      = log(sum_k w_k exp(0))        (:54-62, a constant)
+// The components' tile images are read from global memory (L2): any number of
+// components, no LDS.  No gradient (the reference has none either).
+template <int NT>
+struct MixModel {
+    using Args = MixArgs;
+    using T = Tile<NT>;
+    static constexpr int S = T::S;
+    static constexpr int kImg = tri_tiles(NT) * 64;
+
+    static constexpr __host__ __device__ size_t lds_doubles(bool) { return 0; }
+    static RMH_DEV void setup(double *, const Args &, bool) {}
+
+    template <bool GRAD, bool VALUE = true>
+    static RMH_DEV void eval(const double *, const Args &m, bool, int lane, const double (&th)[S],
+                             double &lp, double (&grad)[S], double (&parts)[2])
+    {
+        static_assert(!GRAD, "MixtureDist has no gradient");
+        const int g = lane >> 4;
+        double acc = 0.0;
+        for (int k = 0; k < m.ncomp; ++k) {
+            asm volatile("" ::: "memory");
+            const double *W = m.Wtiles + (size_t)k * kImg + lane;
+            const double *mu = m.mu_pad + (size_t)k * (4 * S);
+            double y[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) y[s] = th[s] - mu[4 * s + g];
+            double4_t a[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) a[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+            T::template mul_lower<true>(W, y, a, m.ks);
+            double uu = 0.0;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                uu += a[i].x * a[i].x + a[i].y * a[i].y + a[i].z * a[i].z + a[i].w * a[i].w;
+            uu = sum4(uu);
+            const double logLk = -0.5 * ((uu + m.dlog2pi) + m.cst[k]); // gaussian.py:49-52
+            acc += m.wts[k] * exp(logLk);
+        }
+        const double logL = log_full(acc);
+        lp = combine_post(m.logP0, logL);
+        parts[0] = m.logP0;
+        parts[1] = logL;
+        (void)grad;
+    }
+};
+
 // ------------------------------------------------------- logistic regression
 //
 // X streams through LDS in stages of CH = 2 row tiles (32 data rows).  One

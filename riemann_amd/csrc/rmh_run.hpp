@@ -85,7 +85,16 @@ struct AdaptScale {
 // PCN: preconditioned Crank-Nicolson (proposals/randomwalk.py:78-101):
 //   theta' = rho theta + rho_c L xi;  logqratio = -(|u_fwd|^2 - |u_rev|^2)/2 with
 //   u = (rho_c L)^-1 dtheta for dtheta_fwd = theta' - rho theta, dtheta_rev = theta - rho theta'.
-template <class M, int NW, bool ADAPT, bool PCN = false>
+//
+// PT: parallel tempering (PTSampler, samplers/ptsampler.py:42-127).  A wavefront's 16
+// chain slots hold 16/K ensembles of K replicas, rung-minor (slots >= K*(16/K) idle);
+// replica of rung i samples TemperedModel(model, beta_i) (:11-39).  A sweep (:100-125)
+// = one selector uniform per rung (sub-stream 0) deciding between the within-chain MH
+// step and a swap proposal with the next rung (swap uniform: sub-stream 1); the
+// sequential "already swapped" rule (:104-106) is resolved per ensemble from one
+// ballot.  An accepted swap exchanges the two replicas' registers with ds_bpermute
+// (neighbouring lanes of the same 16-lane row): no memory traffic.
+template <class M, int NW, bool ADAPT, bool PCN = false, bool PT = false>
 __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
@@ -111,6 +120,22 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
     T::load_state(ch.theta, ch.ld, c, g, th);
     double lp = ch.logpost[c];
     Xo rng = xo_load(ch.rng, ch.nslots, slot);
+    // PT: rung and ensemble base of this slot; log prior / log likelihood of the state
+    int rung = 0, ebase = 0;
+    bool pt_valid = false;
+    double beta = 1.0, sP = 0.0, sL = 0.0;
+    if (PT) {
+        const int K = run.pt_K;
+        rung = cl % K;
+        ebase = cl - rung;
+        pt_valid = cl < (16 / K) * K;
+        beta = run.pt_beta[c];
+        double dummy0[S], parts0[2], lp0;
+        M::template eval<false>(mlds, m, false, lane, th, lp0, dummy0, parts0);
+        sP = parts0[0];
+        sL = parts0[1];
+        lp = combine_post(sP, beta * sL);   // Sampler.__init__ of the rung, sampler.py:42
+    }
     Keep keep(run);
     keep.record<NT>(run, ch, 0, c, g, active, th, lp);
     AdaptScale ad{0.0, 0.0, 1.0};
@@ -120,6 +145,26 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
         // the tile images never change, so without this fence LICM hoists their
         // ds_reads out of the loop and spends the whole register file on them
         asm volatile("" ::: "memory");
+        bool pt_init = false, pt_partner = false;
+        double vswap = 0.0;
+        if (PT) {
+            // one word of every sub-stream: selector (sub-stream 0), swap uniform (1)
+            const double uw = u01(xo_next(rng));
+            const double usel = __shfl(uw, cl);
+            vswap = __shfl(uw, 16 + cl);
+            // ptsampler.py:107: within-chain iff u > Pswap or last rung
+            const bool wants = pt_valid && rung < run.pt_K - 1 && !(usel > run.pt_pswap);
+            const unsigned wm = (unsigned)(__ballot(wants) & 0xFFFFu) >> ebase;
+            bool prev = false;
+            for (int j = 0; j < run.pt_K; ++j) { // :104-106, rungs in order
+                const bool in = ((wm >> j) & 1u) && !prev;
+                if (j == rung) {
+                    pt_init = in;
+                    pt_partner = prev;
+                }
+                prev = in;
+            }
+        }
         double xi[S];
         T::normals(rng, ch.M, ch.d, g, tab, xi);
         // theta' = theta + scale * L xi        (randomwalk.py:26; logqratio = 0.0)
@@ -159,13 +204,42 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
             T::unpack(acc, thp);
         }
         M::template eval<false>(mlds, m, false, lane, thp, lpp, dummy, parts);
+        if (PT) lpp = combine_post(parts[0], beta * parts[1]); // TemperedModel, ptsampler.py:35-39
         const double u = T::accept_uniform(rng, g, cl);
-        const bool acc_ok = mh_accept(lpp, lp, logq, u);
+        bool acc_ok = mh_accept(lpp, lp, logq, u);
+        if (PT) acc_ok = acc_ok && pt_valid && !pt_init && !pt_partner;
 #pragma unroll
         for (int s = 0; s < S; ++s) th[s] = acc_ok ? thp[s] : th[s];
         lp = acc_ok ? lpp : lp;
+        int code = acc_ok ? 1 : 0;
+        if (PT) {
+            sP = acc_ok ? parts[0] : sP;
+            sL = acc_ok ? parts[1] : sL;
+            // swap proposal between rung i (initiator) and i+1, ptsampler.py:110-125
+            const bool swapper = pt_init || pt_partner;
+            const int src = pt_init ? lane + 1 : pt_partner ? lane - 1 : lane;
+            const double oP = __shfl(sP, src), oL = __shfl(sL, src), ob = __shfl(beta, src);
+            const double olp = __shfl(lp, src), ov = __shfl(vswap, src);
+            const double cross_me = combine_post(oP, beta * oL);  // my model at the other state
+            const double cross_ot = combine_post(sP, ob * sL);    // the other model at my state
+            // (logpost_ji + logpost_ij) - (logpost_ii + logpost_jj): the same bits on both lanes
+            const double delta = (cross_ot + cross_me) - (pt_init ? lp + olp : olp + lp);
+            // U < min(1, exp(D)) restated as log(U) < min(0, D)  (the initiator's uniform)
+            const bool sw_ok = swapper && mh_accept(delta, 0.0, 0.0, pt_partner ? ov : vswap);
+            if (__any(sw_ok)) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const double o = __shfl(th[s], src);
+                    th[s] = sw_ok ? o : th[s];
+                }
+            }
+            sP = sw_ok ? oP : sP;
+            sL = sw_ok ? oL : sL;
+            lp = sw_ok ? cross_me : lp;
+            code = swapper ? (sw_ok ? 3 : 2) : code;
+        }
         if (ADAPT) ad.adapt(acc_ok, ch.adapt_target);
-        if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = acc_ok ? 1 : 0;
+        if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = (uint8_t)code;
         keep.record<NT>(run, ch, t + 1, c, g, active, th, lp);
     }
     if (active) {

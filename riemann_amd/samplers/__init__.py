@@ -1,3 +1,4 @@
 from .sampler import Sampler
+from .ptsampler import PTSampler, TemperedModel
 
-__all__ = ["Sampler"]
+__all__ = ["Sampler", "PTSampler", "TemperedModel"]

@@ -644,3 +644,115 @@ def test_checkpoint_restore_continues_bit_for_bit(ra, tmp_path):
     np.testing.assert_array_equal(th, ref_th)
     np.testing.assert_array_equal(lp, ref_lp)
     np.testing.assert_array_equal(c.proposal.scale, a.proposal.scale)
+
+
+# ------------------------------------------- mixture targets, parallel tempering
+MIX2D = [(0.3, [0.0, 0.0], [[1.0, 0.9], [0.9, 1.0]]),
+         (0.7, [0.0, 0.0], [[1.0, -0.9], [-0.9, 1.0]])]
+
+
+def test_g11_mixture_values_and_random_walk(ra):
+    from riemann_amd.models import benchmarks as b
+    from riemann_amd.proposals import MetropolisRandomWalk
+    z = load("g11_mixture_values")
+    for name, m in (("mix1d", b.benchmark_gauss1d_mix2), ("mix2d", b.benchmark_gauss2d_mix2_cross)):
+        np.testing.assert_array_equal(m._mixweights, z[name + "_weights"])
+        th = z[name + "_theta"]
+        for fn, key in ((m.log_likelihood, "_logL"), (m.log_prior, "_logP"), (m.log_posterior, "_logpost")):
+            got, ref = fn(th), z[name + key]
+            assert np.array_equal(np.isinf(got), np.isinf(ref))
+            fin = np.isfinite(ref)
+            np.testing.assert_allclose(got[fin], ref[fin], rtol=RTOL, atol=1e-15)
+    z = load("g11_mixture_rw")
+    s = ra.Sampler(b.benchmark_gauss2d_mix2_cross, MetropolisRandomWalk(z["Cprop"]), z["theta0"],
+                   seed=int(z["seed"]))
+    s.run(96)
+    check_run(z, s)
+    z = load("g11_mixture1d_rw")
+    s = ra.Sampler(b.benchmark_gauss1d_mix2, MetropolisRandomWalk(z["Cprop"]), z["theta0"],
+                   seed=int(z["seed"]))
+    s.run(96)
+    check_run(z, s)
+    with pytest.raises(ra.ParameterError):
+        b.benchmark_gauss2d_mix2_cross.grad_log_posterior(np.zeros(2))
+
+
+def check_pt(z, pt):
+    idx = z["slots"]
+    th = np.transpose(pt._host_thetas, (0, 1, 2, 3))          # (n, Ne, K, d)
+    np.testing.assert_allclose(th, z["thetas"][:, idx], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(pt._host_logpost, z["logpost"][:, idx], rtol=RTOL)
+    code = pt._host_codes
+    sp, sa, wa = z["swap_prop"][:, idx], z["swap_acc"][:, idx], z["within_acc"][:, idx]
+    np.testing.assert_array_equal(code >> 1, sp)
+    sw = sp == 1
+    known = sa >= 0
+    np.testing.assert_array_equal((code & 1)[sw & known], sa[sw & known])
+    np.testing.assert_array_equal((code & 1)[~sw], wa[~sw])
+
+
+def test_g12_parallel_tempering_vs_reference_fixture(ra):
+    from riemann_amd.models import MultiGaussianDist, benchmarks as b
+    from riemann_amd.proposals import MetropolisRandomWalk
+    from riemann_amd.samplers import PTSampler
+    z = load("g12_pt_gauss2d")
+    pt = PTSampler(MultiGaussianDist(z["mu"], z["C"]), MetropolisRandomWalk(z["Cprop"]), z["theta0"],
+                   Pswap=float(z["pswap"]), seed=int(z["seed"]))
+    np.testing.assert_array_equal(pt.betas, z["betas"])
+    pt.run(40)
+    pt.run(56)          # the histories continue across run() calls
+    check_pt(z, pt)
+    assert pt._chain_thetas.shape == (97, 4, 2)
+    z = load("g12_pt_mix2d")
+    pt = PTSampler(b.benchmark_gauss2d_mix2_cross, MetropolisRandomWalk(z["Cprop"]), z["theta0"],
+                   Pswap=float(z["pswap"]), seed=int(z["seed"]))
+    for _ in range(3):
+        pt.sample()
+    pt.run(93)
+    check_pt(z, pt)
+    # a single ensemble keeps the reference's shapes; rung views expose the tempered models
+    pt1 = PTSampler(b.benchmark_gauss2d_mix2_cross, MetropolisRandomWalk(z["Cprop"]), z["theta0"][0],
+                    Pswap=0.1, seed=int(z["seed"]))
+    pt1.run(10)
+    assert pt1._chain_thetas.shape == (11, 2) and pt1._chain_logpost.shape == (11,)
+    np.testing.assert_allclose(pt1._chain_thetas, z["thetas"][:11, z["slots"][0, 0]], rtol=RTOL, atol=1e-12)
+    th, lp = pt1.samplers[2].current_state()
+    np.testing.assert_allclose(lp, pt1.samplers[2].model.log_posterior(th), rtol=RTOL)
+    with pytest.raises(ra.ParameterError):
+        PTSampler(b.benchmark_gauss2d_mix2_cross, MetropolisRandomWalk(z["Cprop"]), z["theta0"], Pswap=1.5)
+    with pytest.raises(ra.ParameterError):
+        PTSampler(b.benchmark_gauss2d_mix2_cross, MetropolisRandomWalk(z["Cprop"]), z["theta0"], betas=[1.0, 2.0])
+
+
+@pytest.mark.parametrize("K,d", [(5, 100), (4, 100), (16, 3), (3, 40), (1, 2)])
+def test_parallel_tempering_many_ensembles_vs_oracle(ra, orc, K, d):
+    """Thousands of ladders against the oracle: states, tempered log posteriors, codes."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    from riemann_amd.samplers import PTSampler
+    g = np.random.default_rng(K * 100 + d)
+    A = g.standard_normal((d, d))
+    Cm = A @ A.T / d + 0.5 * np.eye(d)
+    mu = g.standard_normal(d)
+    Cp = (2.38 ** 2 / d) * Cm
+    Ne, T = 700, 24
+    betas = 0.6 ** np.arange(K)
+    th0 = g.standard_normal((Ne, d))
+    pt = PTSampler(MultiGaussianDist(mu, Cm), MetropolisRandomWalk(Cp), th0, betas=betas, Pswap=0.25,
+                   seed=5, chain0=4096)
+    pt.run(T)
+    S, idx = orc.pt_slots(Ne, K)
+    slots = np.zeros((S, d))
+    slots[idx] = th0[:, None, :]
+    st = orc.rng_seed(5, S, chain0=4096)
+    ht, hl, code, _ = orc.run_pt(orc.Gaussian(mu, Cm), orc.RandomWalk(Cp), slots, st, T, betas, 0.25)
+    np.testing.assert_array_equal(pt._host_codes, code[:, idx])
+    np.testing.assert_allclose(pt._host_thetas, ht[:, idx], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(pt._host_logpost, hl[:, idx], rtol=RTOL)
+    if K > 1:
+        assert (code[:, idx] == 3).sum() > 100 and (code[:, idx] == 2).sum() > 10
+    # resumable stream: the slots' stream states agree with the oracle's afterwards
+    rng = np.empty((S, 16), dtype=np.uint64)
+    from riemann_amd import _lib
+    _lib.call("rmh_state_get_rng", pt._state, rng)
+    np.testing.assert_array_equal(rng[idx.ravel()], st[idx.ravel()])

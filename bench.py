@@ -76,6 +76,18 @@ def workload(name, chains):
                     label="cfg5: changepoint k=5 (n=100), random-walk MH",
                     omodel=lambda o: o.Changepoint(x, y, k, 1.0, 3.0, 5.0, 1.0, 1.0),
                     oprop=lambda o: o.RandomWalk(np.diag(cdiag), 0.1), cpu_sample=(65536, 400))
+    if name == "pt_gauss":      # PTSampler, default ladder, on the cfg2 target
+        d, K = 100, 5
+        Ct = W.corr_gauss_cov(d)
+        Cp = (2.38 ** 2 / d) * Ct
+        ne = (chains // 16) * (16 // K)          # `chains` slots hold 16//K ladders per 16
+        th0 = np.random.default_rng(1).standard_normal((ne, d)) @ np.linalg.cholesky(Ct).T
+        return dict(model=MultiGaussianDist(np.zeros(d), Ct), proposal=MetropolisRandomWalk(Cp),
+                    theta0=th0, d=d, iters=1000, flops=2 * d * (d + 1) + 4 * d, bytes=8 * (d + 1),
+                    bound="mfma", pt=dict(betas=0.5 ** np.arange(K), pswap=0.1),
+                    label="8f-2: parallel tempering, 5 temperatures, 100-d correlated Gaussian, random-walk MH",
+                    omodel=lambda o: o.Gaussian(np.zeros(d), Ct), oprop=lambda o: o.RandomWalk(Cp),
+                    cpu_sample=(240, 2000))
     raise SystemExit("unknown workload " + name)
 
 
@@ -98,6 +110,18 @@ def cpu_baseline(w, seed):
     N, T = w["cpu_sample"]
     N = min(N, w["theta0"].shape[0])
     m, p = w["omodel"](orc), w["oprop"](orc)
+    if "pt" in w:   # N ladders, serial restatement of PTSampler.run
+        K = len(w["pt"]["betas"])
+        S, idx = orc.pt_slots(N, K)
+        th = np.zeros((S, w["d"]))
+        th[idx] = w["theta0"][:N, None, :]
+        st = orc.rng_seed(seed, S)
+        t0 = time.perf_counter()
+        orc.run_pt(m, p, th, st, T, w["pt"]["betas"], w["pt"]["pswap"], history=False)
+        dt = time.perf_counter() - t0
+        return {"value": N * K * T / dt, "unit": "chain-iterations/s", "cores": 1, "kind": "port",
+                "sample": "%d ladders x %d temperatures x %d sweeps, oracle/rmh_oracle.c orc_run_pt "
+                          "(one thread), %.1f s" % (N, K, T, dt)}
     th = np.ascontiguousarray(w["theta0"][:N]).copy()
     st = orc.rng_seed(seed, N)
     lp = m.log_posterior(th)
@@ -141,7 +165,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="gauss_rw",
-                    choices=["gauss_rw", "logreg_mala", "logreg_hmc", "changepoint_rw"])
+                    choices=["gauss_rw", "logreg_mala", "logreg_hmc", "changepoint_rw", "pt_gauss"])
     ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
     ap.add_argument("--iters", type=int, default=0, help="MH iterations per step (0 = workload default)")
     ap.add_argument("--seed", type=int, default=1)
@@ -178,15 +202,27 @@ def main():
     N, d = w["theta0"].shape
 
     # chains of this rank: global ids [rank*N, (rank+1)*N) -- RNG keyed by global id
-    s = ra.Sampler(w["model"], w["proposal"], w["theta0"], seed=a.seed, chain0=rank * N)
+    pt = w.get("pt")
+    if pt:   # N ladders of K replicas in S chain slots; streams keyed by global slot id
+        from riemann_amd.samplers import PTSampler
+        s = PTSampler(w["model"], w["proposal"], w["theta0"], betas=pt["betas"], Pswap=pt["pswap"],
+                      seed=a.seed, chain0=rank * a.chains)
+        K = s.Ntemps
+        bet = _lib.as_f64(s.betas)
+    else:
+        s = ra.Sampler(w["model"], w["proposal"], w["theta0"], seed=a.seed, chain0=rank * N)
     hist = C.c_void_p()
     if not a.no_record:
         _lib.call("rmh_history_create", s._state, iters + 1, iters, C.byref(hist))
     w["proposal"]._sync()
 
     def step():
-        _lib.call("rmh_run", w["model"]._h, w["proposal"]._h, s._state, iters, 0, 1,
-                  hist if hist else None)
+        if pt:
+            _lib.call("rmh_run_pt", w["model"]._h, w["proposal"]._h, s._state, bet, K, pt["pswap"],
+                      iters, 0, 1, hist if hist else None)
+        else:
+            _lib.call("rmh_run", w["model"]._h, w["proposal"]._h, s._state, iters, 0, 1,
+                      hist if hist else None)
 
     def barrier():
         _lib.call("rmh_synchronize")
@@ -226,7 +262,7 @@ def main():
     if dist is not None:
         try:
             from riemann_amd.distributed import pool_samples, pooled_moments
-            th, lp = s.current_state()
+            th, lp = s.current_state()          # PT: the beta = 1 rung of every ladder
             allth = pool_samples(th, world * N, device=cdev)        # RCCL all-gather over xGMI
             mean, cov = pooled_moments(th, device=cdev)             # RCCL all-reduce
             pooled = {"allgather_bytes_per_rank": int(th.size * 8),
@@ -240,6 +276,8 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
+    if pt:
+        N = N * K                # replicas: every one makes a within-chain or a swap move per sweep
     total_iters = world * N * iters * a.steps
     value = total_iters / dt
     kms = float(np.mean(kernel_ms))
@@ -270,7 +308,11 @@ def main():
         out["pool"] = pooled
     if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed at N=1 only
         out["cpu_baseline"] = cpu_baseline(w, a.seed)
-    if not a.no_ess and world == 1:
+    if pt:
+        out["config"]["ladders_per_gpu"] = N // K
+        out["config"]["temperatures"] = K
+        out["config"]["chain_slots_per_gpu"] = a.chains
+    if not a.no_ess and world == 1 and not pt:
         try:
             tau, acc = tau_estimate(w, a.seed)
             out["ess"] = {"tau_int_max": tau, "accept_rate": acc, "ess_per_sec": value / tau,

@@ -68,7 +68,8 @@ hipError_t launch_gauss_pt(int NT, const GaussArgs &m, const RwArgs &p, const Ch
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
         const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false) + kIcdfDoubles);
-        return launch(k_run_rw<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
+        constexpr int NW = (kNT >= 7) ? 8 : 4;
+        return launch(k_run_rw<M, NW, false, false, true>, c.nblocks, NW, lds, st, m, p, c, r);
     })
 }
 

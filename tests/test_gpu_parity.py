@@ -756,3 +756,25 @@ def test_parallel_tempering_many_ensembles_vs_oracle(ra, orc, K, d):
     from riemann_amd import _lib
     _lib.call("rmh_state_get_rng", pt._state, rng)
     np.testing.assert_array_equal(rng[idx.ravel()], st[idx.ravel()])
+
+
+def test_parallel_tempering_shards_by_tile(ra):
+    """Ladders split over two 'ranks' at a tile boundary (chain0 = first global slot) give
+    the same chains as one rank: streams are keyed by global slot id."""
+    from riemann_amd.models import benchmarks as b
+    from riemann_amd.proposals import MetropolisRandomWalk
+    from riemann_amd.samplers import PTSampler
+    m, Cp = b.benchmark_gauss2d_mix2_cross, 1.5 * np.eye(2)
+    th0 = np.random.default_rng(3).standard_normal((96, 2))
+    one = PTSampler(m, MetropolisRandomWalk(Cp), th0, seed=9)
+    one.run(50)
+    parts = []
+    for r in range(2):          # 48 ladders of 5 = 16 tiles = 256 slots per rank
+        p = PTSampler(m, MetropolisRandomWalk(Cp), th0[48 * r:48 * (r + 1)], seed=9, chain0=256 * r)
+        p.run(50)
+        parts.append(p)
+    np.testing.assert_array_equal(one._chain_thetas, np.concatenate([p._chain_thetas for p in parts], axis=1))
+    np.testing.assert_array_equal(one._host_codes, np.concatenate([p._host_codes for p in parts], axis=1))
+    # the cold rung mixes between the two crossed components: both signs of x*y are visited
+    xy = one._chain_thetas[10:, :, 0] * one._chain_thetas[10:, :, 1]
+    assert (xy > 0.2).mean() > 0.1 and (xy < -0.2).mean() > 0.2

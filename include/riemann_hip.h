@@ -88,6 +88,14 @@ int rmh_grad_log_posterior(rmh_model_t m, const double *theta, int64_t N, double
 /* ---- Proposal: riemann/proposals/proposal.py:1-26 ----------------------- */
 /* MetropolisRandomWalk(C), proposals/randomwalk.py:17-26.  L = cholesky(C). */
 int rmh_proposal_rw_create(const double *L, int d, double scale, rmh_proposal_t *out);
+/* ChangepointRegression1DProp.propose at fixed k, riemann/test_changepoint.py:18-56: the d
+ * coordinates are cut into nblk <= 3 consecutive blocks (cpx, cpv, sig: sizes k, k+1, 1), each
+ * with its own MetropolisRandomWalk (:36-41; L must be block diagonal); chained independent
+ * uniforms pick the block: block b iff u_b < pcum[b] and no earlier block was picked
+ * (:47-55, pcum = P_cumprop_cpx, _cpv, _sig).  No block picked = the reference's
+ * trans-dimensional branch (:56-71), which does not exist at fixed k: theta' = theta.
+ * nblk = 0 returns to the full-vector random walk.  (Changepoint model, fused run only.) */
+int rmh_proposal_rw_set_blocks(rmh_proposal_t p, int nblk, const int *sizes, const double *pcum);
 /* pCN(C, rho), proposals/randomwalk.py:78-101.  L = cholesky(C).  (Gaussian model,
  * fused run only.) */
 int rmh_proposal_pcn_create(const double *L, int d, double rho, rmh_proposal_t *out);

@@ -72,11 +72,14 @@ def lib():
     L.orc_run_adapt.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, vp, vp, vp, i32, vp]
     L.orc_run.restype = i32
     L.orc_run.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, vp, vp, vp, i32]
+    L.orc_rng_normals.argtypes = [_u64p, i32, _f64p]
+    L.orc_rng_words.argtypes = [_u64p, _f64p]
     L.orc_rng_pt_stream.argtypes = [_u64p, i64, i32, i32, _f64p, _f64p, _f64p, _f64p]
     L.orc_model_mixture.restype = vp
     L.orc_model_mixture.argtypes = [_f64p, _f64p, _f64p, i32, i32, dbl]
     L.orc_run_pt.restype = i32
     L.orc_run_pt.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, _f64p, i32, dbl, vp, vp, vp]
+    L.orc_proposal_set_blocks.argtypes = [vp, i32, _i32p, _f64p]
     L.orc_max_threads.restype = i32
     _lib = L
     return L
@@ -101,6 +104,20 @@ def rng_stream(state, d, T):
     u = np.empty((T, N))
     lib().orc_rng_stream(state, N, d, T, xi, u)
     return xi, u
+
+
+def rng_normals(state, d):
+    """The next d normals of ONE chain (state (1,16), advanced in place)."""
+    xi = np.empty(d)
+    lib().orc_rng_normals(state, d, xi)
+    return xi
+
+
+def rng_words(state):
+    """One more word from each of the four sub-streams of ONE chain, as U[0,1) doubles."""
+    u = np.empty(4)
+    lib().orc_rng_words(state, u)
+    return u
 
 
 def rng_pt_stream(state, d, T):
@@ -226,6 +243,15 @@ class RandomWalk(_Proposal):
         Lc = _c(np.linalg.cholesky(np.atleast_2d(Cov)))
         self.d = Lc.shape[0]
         self._h = lib().orc_proposal_rw(Lc, self.d, float(scale))
+
+
+class BlockRandomWalk(RandomWalk):
+    """ChangepointRegression1DProp at fixed k (/root/reference/riemann/test_changepoint.py:18-56):
+    blocks of consecutive coordinates, block b picked iff u_b < pcum[b] and none before it."""
+
+    def __init__(self, Cov, sizes, pcum, scale=1.0):
+        super().__init__(Cov, scale)
+        lib().orc_proposal_set_blocks(self._h, len(sizes), _c(sizes, np.int32), _c(pcum))
 
 
 class PCN(_Proposal):

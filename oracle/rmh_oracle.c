@@ -176,6 +176,12 @@ void orc_rng_normals(u64 *st, int d, double *xi)
 /* U[0,1) from sub-stream 0 */
 double orc_rng_uniform(u64 *st) { return (double)(orc_next(st) >> 11) * ORC_2M53; }
 
+/* one word from each sub-stream of one chain, as U[0,1) */
+void orc_rng_words(u64 *st, double *u)
+{
+    for (int g = 0; g < 4; g++) u[g] = (double)(orc_next(st + 4 * g) >> 11) * ORC_2M53;
+}
+
 void orc_rng_seed(u64 seed, u64 chain0, int64_t N, u64 *state)
 {
     for (int64_t c = 0; c < N; c++)
@@ -508,6 +514,9 @@ typedef struct orc_proposal {
     double adapt_target; /* > 0: AdaptScaleProposal mix-in, proposals/adaptive.py:11-35 */
     double *chM;         /* cholesky(M) when a mass matrix is given, hamiltonian.py:71-74 */
     double rho, rho_c;   /* pCN, randomwalk.py:83-87 */
+    /* block-mixture random walk, ChangepointRegression1DProp (riemann/test_changepoint.py:18-56) */
+    int nblk, blk_end[3];
+    double blk_p[3];
 } orc_proposal;
 
 orc_proposal *orc_proposal_rw(const double *L, int d, double scale)
@@ -515,6 +524,26 @@ orc_proposal *orc_proposal_rw(const double *L, int d, double scale)
     orc_proposal *p = (orc_proposal *)calloc(1, sizeof(*p));
     p->kind = ORC_RW; p->d = d; p->L = orc_dup(L, (size_t)d * d); p->scale = scale;
     return p;
+}
+
+/* ChangepointRegression1DProp.propose at fixed k (riemann/test_changepoint.py:43-56): the
+ * coordinates are cut into nblk <= 3 consecutive blocks (cpx, cpv, sig) of the given sizes,
+ * each with its own MetropolisRandomWalk (:36-41; L must be block diagonal); CHAINED
+ * independent uniforms pick the block: block b iff u_b < pcum[b] and no earlier block was
+ * picked (:47-55).  If none is picked the reference makes a trans-dimensional move (:56-71),
+ * which does not exist at fixed k: the proposal is then theta itself.
+ * Stream: after the iteration's normals every sub-stream draws one more word; sub-stream
+ * 0's is the accept uniform as always, those of sub-streams 1, 2, 3 are u_0, u_1, u_2.  The
+ * picked block uses the normals of its own coordinates. */
+void orc_proposal_set_blocks(orc_proposal *p, int nblk, const int *sizes, const double *pcum)
+{
+    p->nblk = nblk;
+    int end = 0;
+    for (int b = 0; b < nblk; b++) {
+        end += sizes[b];
+        p->blk_end[b] = end;
+        p->blk_p[b] = pcum[b];
+    }
 }
 
 /* pCN(C, rho): proposals/randomwalk.py:78-101.  L = cholesky(C). */
@@ -710,6 +739,17 @@ int orc_run_adapt(const orc_model *m, const orc_proposal *p, int64_t N, double *
             if (hist_logpost) hist_logpost[c] = logpost[c];
             for (int t = 0; t < T; t++) {
                 orc_rng_normals(st, d, xi);
+                if (p->nblk > 0) { /* block pick, test_changepoint.py:47-55 */
+                    int pick = -1;
+                    for (int b = 0; b < 3; b++) {
+                        const double ub = (double)(orc_next(st + 4 * (b + 1)) >> 11) * ORC_2M53;
+                        if (pick < 0 && b < p->nblk && ub < p->blk_p[b]) pick = b;
+                    }
+                    const int lo = pick <= 0 ? 0 : p->blk_end[pick - 1];
+                    const int hi = pick < 0 ? 0 : p->blk_end[pick];
+                    for (int j = 0; j < d; j++)
+                        if (j < lo || j >= hi) xi[j] = 0.0;
+                }
                 const double logq = orc_propose1(p, m, th, xi, thp, w2, adapt ? adapt[3 * c + 2] : 1.0);
                 const double lp_prop = orc_log_post1(m, thp, w2);
                 const double delta = lp_prop - logpost[c] - logq;

@@ -19,6 +19,7 @@ RMH_OK, RMH_ERR_PARAM, RMH_ERR_HIP, RMH_ERR_STATE = 0, 1, 2, 3
 _f64 = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _u64 = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 _u8 = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_i32 = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _vp, _i64, _u64s, _dbl, _int = C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_int
 _pvp = C.POINTER(C.c_void_p)
 
@@ -40,6 +41,7 @@ SIGNATURES = {
     "rmh_log_posterior": [_vp, _f64, _i64, _f64],
     "rmh_grad_log_posterior": [_vp, _f64, _i64, _f64],
     "rmh_proposal_rw_create": [_f64, _int, _dbl, _pvp],
+    "rmh_proposal_rw_set_blocks": [_vp, _int, _i32, _f64],
     "rmh_proposal_pcn_create": [_f64, _int, _dbl, _pvp],
     "rmh_proposal_hmc_create": [_dbl, _int, _int, _pvp],
     "rmh_proposal_hmc_set_mass": [_vp, _vp],

@@ -139,6 +139,8 @@ struct rmh_proposal {
     double *d_Ltiles = nullptr;
     bool dirty = true;
     double *d_chM = nullptr, *d_V = nullptr, *d_VT = nullptr; // mass-matrix tile images (HMC)
+    int nblk = 0, blk_end[3] = {0, 0, 0};                     // block-mixture random walk
+    double blk_p[3] = {0.0, 0.0, 0.0};
 };
 
 struct rmh_state {
@@ -659,6 +661,39 @@ int rmh_proposal_rw_create(const double *L, int d, double scale, rmh_proposal_t 
     return RMH_OK;
 }
 
+int rmh_proposal_rw_set_blocks(rmh_proposal_t p, int nblk, const int *sizes, const double *pcum)
+{
+    if (!p || p->kind != kRW) return fail(RMH_ERR_PARAM, "set_blocks: not a random-walk proposal");
+    if (nblk == 0) {
+        p->nblk = 0;
+        return RMH_OK;
+    }
+    if (nblk < 1 || nblk > 3 || !sizes || !pcum) return fail(RMH_ERR_PARAM, "set_blocks: 1 to 3 blocks");
+    int end = 0;
+    for (int b = 0; b < nblk; ++b) {
+        if (sizes[b] < 1) return fail(RMH_ERR_PARAM, "set_blocks: empty block");
+        end += sizes[b];
+    }
+    if (end != p->d) return fail(RMH_ERR_PARAM, "set_blocks: the blocks must cover the d coordinates");
+    // every block has its own MetropolisRandomWalk (test_changepoint.py:36-41): L block diagonal
+    end = 0;
+    for (int b = 0; b < nblk; ++b) {
+        for (int i = end; i < end + sizes[b]; ++i)
+            for (int j = 0; j < end; ++j)
+                if (p->L[(size_t)i * p->d + j] != 0.0)
+                    return fail(RMH_ERR_PARAM, "set_blocks: L is not block diagonal over the blocks");
+        end += sizes[b];
+    }
+    end = 0;
+    for (int b = 0; b < 3; ++b) {
+        if (b < nblk) end += sizes[b];
+        p->blk_end[b] = end;
+        p->blk_p[b] = b < nblk ? pcum[b] : 0.0;
+    }
+    p->nblk = nblk;
+    return RMH_OK;
+}
+
 int rmh_proposal_pcn_create(const double *L, int d, double rho, rmh_proposal_t *out)
 {
     RMH_NEED_INIT();
@@ -779,6 +814,8 @@ int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
     if (e == hipSuccess) {
         if (p->kind == kPCN) {
             rc = fail(RMH_ERR_PARAM, "propose: stand-alone pCN proposals are not built");
+        } else if (p->kind == kRW && p->nblk > 0) {
+            rc = fail(RMH_ERR_PARAM, "propose: stand-alone block-mixture proposals are not built");
         } else if (p->kind == kRW) {
             rc = sync_proposal(p);
             if (!rc) {
@@ -1136,6 +1173,15 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         e = launch_gauss_pcn(m->NT, m->ga, ra, c, r, g_stream);
     } else if (p->kind == kRW) {
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
+        if (p->nblk > 0) {
+            if (m->kind != kChangepoint || adapt)
+                return fail(RMH_ERR_PARAM, "run: block-mixture proposals are built for the changepoint model only");
+            ra.nblk = p->nblk;
+            for (int b = 0; b < 3; ++b) {
+                ra.blk_end[b] = p->blk_end[b];
+                ra.blk_p[b] = p->blk_p[b];
+            }
+        }
         if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
         else if (m->kind == kChangepoint) e = launch_cp_rw(m->k, m->ca, ra, c, r, g_stream);
         else if (m->kind == kMixture && !adapt) e = launch_mix_rw(m->NT, m->ma, ra, c, r, g_stream);

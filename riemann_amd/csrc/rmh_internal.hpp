@@ -85,6 +85,12 @@ struct RwArgs {
     const double *Ltiles; // lower-triangular tile image of scale*L (rho_c*L for pCN), staged in LDS
     const double *Vtiles; // pCN: tile image of (rho_c*L)^-1, read from global memory (L2)
     double rho;           // pCN (proposals/randomwalk.py:83-86)
+    // block-mixture random walk (ChangepointRegression1DProp, riemann/test_changepoint.py:18-56):
+    // nblk <= 3 consecutive coordinate blocks ending at blk_end[b], picked by chained
+    // uniforms against blk_p[b]; nblk = 0: plain full-vector random walk
+    int nblk;
+    int blk_end[3];
+    double blk_p[3];
 };
 
 struct HmcArgs {

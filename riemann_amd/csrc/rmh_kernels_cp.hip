@@ -139,7 +139,12 @@ RMH_DEV void cp_load(const double *theta, int64_t ld, int64_t c, double (&th)[D]
 // 512-thread workgroups, two per CU (LDS: 47.5 KB each) = 4 waves per SIMD: the
 // kernel is latency-bound (41 % of wave cycles parked on s_waitcnt at 2 waves per
 // SIMD), so occupancy pays: +22 % over 256-thread workgroups.
-template <int KC>
+// BLOCK: the block-mixture proposal of ChangepointRegression1DProp.propose at fixed k
+// (riemann/test_changepoint.py:43-56): after the normals every sub-stream draws one more
+// word -- sub-stream 0's is the accept uniform, those of sub-streams 1..3 the chained block
+// selectors (:47-51) -- and only the picked block's normals enter theta + L xi (L is block
+// diagonal); no block picked (the reference's trans-dimensional branch): theta' = theta.
+template <int KC, bool BLOCK>
 __global__ void __launch_bounds__(512, 4) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
     using M = CpModel<KC>;
@@ -185,6 +190,19 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs
         // 4-lanes-per-chain tile; then the chain's lanes exchange their quarters
         double xi[S];
         T::normals(rng, ch.M, D, g, tab, xi);
+        double ublk = 0.0;
+        if (BLOCK) {
+            ublk = u01(xo_next(rng));
+            const double u0 = __shfl(ublk, 16 + cl), u1 = __shfl(ublk, 32 + cl), u2 = __shfl(ublk, 48 + cl);
+            int pk = -1;
+            if (pr.nblk > 2 && u2 < pr.blk_p[2]) pk = 2;
+            if (pr.nblk > 1 && u1 < pr.blk_p[1]) pk = 1;
+            if (pr.nblk > 0 && u0 < pr.blk_p[0]) pk = 0;
+            const int lo = pk <= 0 ? 0 : pr.blk_end[pk == 2 ? 1 : 0];
+            const int hi = pk < 0 ? 0 : pr.blk_end[pk];
+#pragma unroll
+            for (int s = 0; s < S; ++s) xi[s] = (4 * s + g >= lo && 4 * s + g < hi) ? xi[s] : 0.0;
+        }
         double4_t acc[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -206,7 +224,7 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs
             const double logL = M::template log_lik<true>(xy, m, thp, g);
             lpp = combine_post(logP, logL); // model.py:49-55
         }
-        const double u = T::accept_uniform(rng, g, cl);
+        const double u = BLOCK ? __shfl(ublk, cl) : T::accept_uniform(rng, g, cl);
         const bool ok = mh_accept(lpp, lp, 0.0, u);
         if (ok) {
 #pragma unroll
@@ -258,7 +276,8 @@ static hipError_t cp_rw_launch(const CpArgs &m, const RwArgs &p, const ChainArgs
     const size_t lds = sizeof(double) * (2 * (size_t)m.n + tri_tiles(NT) * 64 + kIcdfDoubles);
     const int nw = 8;
     const dim3 grid((unsigned)((c.nblocks + nw - 1) / nw));
-    hipLaunchKernelGGL(k_cp_rw<KC>, grid, dim3(64 * nw), lds, st, m, p, c, r);
+    if (p.nblk > 0) hipLaunchKernelGGL((k_cp_rw<KC, true>), grid, dim3(64 * nw), lds, st, m, p, c, r);
+    else hipLaunchKernelGGL((k_cp_rw<KC, false>), grid, dim3(64 * nw), lds, st, m, p, c, r);
     return hipGetLastError();
 }
 

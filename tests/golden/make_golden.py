@@ -542,6 +542,113 @@ def g12_pt():
     save("g12_pt_mix2d", Cprop=1.5 * np.eye(2), **r)
 
 
+class BlockReplay:
+    """Feeds one chain's draws to the reference's ChangepointRegression1DProp + Sampler:
+    the uniforms asked for inside ``propose`` (riemann/test_changepoint.py:47-51) are the
+    block selectors u_0, u_1, u_2 of the iteration, in order; the block's normals are the
+    iteration's normals of that block's coordinates; the uniform asked for by
+    Sampler.sample (sampler.py:84) is the accept uniform and closes the iteration."""
+
+    def __init__(self, xi, usel, ua, ends):
+        self.xi, self.usel, self.ua, self.ends = xi, usel, ua, ends   # (T,d), (T,3), (T,), block ends
+        self.t, self.nsel = 0, 0
+        self.picked = np.full(len(ua), -1, dtype=np.int8)
+
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        b = self.nsel - 1
+        lo, hi = (0 if b == 0 else self.ends[b - 1]), self.ends[b]
+        v = self.xi[self.t, lo:hi]
+        shape = (size,) if np.isscalar(size) else tuple(size)
+        assert v.shape == shape, (v.shape, shape, b)
+        self.picked[self.t] = b
+        return v.copy()
+
+    def uniform(self, low=0.0, high=1.0, size=None):
+        assert size is None
+        fr = sys._getframe(1)
+        if fr.f_code.co_name == "propose":
+            assert fr.f_code.co_filename.endswith("test_changepoint.py") and (low, high) == (0.0, 1.0)
+            self.nsel += 1
+            return float(self.usel[self.t, self.nsel - 1])
+        assert fr.f_code.co_filename.endswith("sampler.py"), fr.f_code.co_filename
+        v = float(self.ua[self.t])
+        self.t += 1
+        self.nsel = 0
+        return v
+
+
+def g13_changepoint_block_proposal():
+    """a-11 variant (B): the reference's own ChangepointRegression1DProp
+    (riemann/test_changepoint.py:18-73) driving its Sampler at fixed k.  P_cumprop_cpv is
+    set to 1.0 (a public attribute, :30): blocks are picked with P(cpx) = 0.2, P(cpv) = 0.8.
+    The sig block cannot be recorded: its MetropolisRandomWalk returns a (1,)-array for the
+    0-d sig (randomwalk.py:22,26), after which Model.log_posterior's np.any([...])
+    (model.py:50) raises "inhomogeneous shape" under numpy >= 1.24 -- an ordinary failure of
+    the reference in this environment; that block is covered by the oracle, whose block
+    logic this fixture pins.  The trans-dimensional branch (:56-71) does not exist at fixed k."""
+    import importlib.util
+    cp = import_changepoint()
+    import riemann.models as rmodels
+    import riemann.proposals as rprops
+    # the script's `from riemann.models import ...` / `from riemann.proposals import ...`
+    # (test_changepoint.py:14-15) expect names the (empty) package __init__ files never bind
+    rmodels.ChangepointParams, rmodels.ChangepointRegression1D = cp.ChangepointParams, cp.ChangepointRegression1D
+    rprops.MetropolisRandomWalk = MetropolisRandomWalk
+    spec = importlib.util.spec_from_file_location("riemann_ref_test_changepoint",
+                                                  "/root/reference/riemann/test_changepoint.py")
+    tc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tc)
+    k = 5
+    model, x, y, truth, Cdiag = changepoint_setup(cp)
+    hscale = 2.0                                   # hmax - hmin, test_changepoint.py:148
+    d = 2 * k + 2
+    ends = [k, 2 * k + 1, d]
+    g = np.random.default_rng(13)
+    N, T = 4, 160
+    th0 = truth + 0.01 * g.standard_normal((N, d))
+    th0[:, :k] = np.sort(th0[:, :k], axis=1)
+    st = orc.rng_seed(130, N)
+    xi = np.empty((T, N, d)); usel = np.empty((T, N, 3)); ua = np.empty((T, N))
+    for t in range(T):                             # normals, then one word per sub-stream
+        x1, _ = None, None
+        for c in range(N):
+            s1 = st[c:c + 1]
+            xi[t, c] = orc.rng_normals(s1, d)
+            w = orc.rng_words(s1)
+            ua[t, c], usel[t, c] = w[0], w[1:]
+    thetas = np.zeros((T + 1, N, d)); logpost = np.zeros((T + 1, N))
+    accept = np.zeros((T, N), dtype=np.uint8); picked = np.zeros((T, N), dtype=np.int8)
+    real_normal, real_uniform = np.random.normal, np.random.uniform
+    import contextlib, io
+    try:
+        for c in range(N):
+            rp = BlockReplay(xi[:, c], usel[:, c], ua[:, c], ends)
+            np.random.normal, np.random.uniform = rp.normal, rp.uniform
+            prop = tc.ChangepointRegression1DProp(model, hscale)
+            prop.P_cumprop_cpv = 1.0
+            t0 = cp.ChangepointParams(th0[c, :k], th0[c, k:2 * k + 1], th0[c, 2 * k + 1])
+            s = Sampler(model, prop, t0)
+            with contextlib.redirect_stdout(io.StringIO()):
+                s.run(T)
+            assert rp.t == T
+            for e, (tt, lp) in enumerate(zip(s._chain_thetas, s._chain_logpost)):
+                thetas[e, c] = np.concatenate([np.ravel(tt.cpx), np.ravel(tt.cpv), np.ravel(tt.sig)])
+                logpost[e, c] = lp
+            accept[:, c] = [s._chain_thetas[t + 1] is not s._chain_thetas[t] for t in range(T)]
+            picked[:, c] = rp.picked
+            Cd = np.concatenate([np.diag(prop.cpx_prop.L) ** 2, np.diag(prop.cpv_prop.L) ** 2,
+                                 np.diag(prop.cps_prop.L) ** 2])
+    finally:
+        np.random.normal, np.random.uniform = real_normal, real_uniform
+    np.testing.assert_allclose(Cd, Cdiag, rtol=1e-14)
+    assert set(np.unique(picked)) == {0, 1}
+    save("g13_changepoint_block", x=x, y=y, k=np.int64(k), xmin=np.float64(1.0), xmax=np.float64(3.0),
+         lamb=np.float64(k), alpha=np.float64(1.0), beta=np.float64(1.0), hscale=np.float64(hscale),
+         Cdiag=Cd, sizes=np.array([k, k + 1, 1], dtype=np.int32), pcum=np.array([0.2, 1.0, 0.6]),
+         seed=np.uint64(130), theta0=th0, thetas=thetas, logpost=logpost, accept=accept,
+         picked=picked, usel=usel, ua=ua)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # regenerate selected fixtures: make_golden.py g11_mixture g12_pt
         for name in sys.argv[1:]:
@@ -560,3 +667,4 @@ if __name__ == "__main__":
     g10_pcn()
     g11_mixture()
     g12_pt()
+    g13_changepoint_block_proposal()

@@ -778,3 +778,50 @@ def test_parallel_tempering_shards_by_tile(ra):
     # the cold rung mixes between the two crossed components: both signs of x*y are visited
     xy = one._chain_thetas[10:, :, 0] * one._chain_thetas[10:, :, 1]
     assert (xy > 0.2).mean() > 0.1 and (xy < -0.2).mean() > 0.2
+
+
+# ---------------------------------- a-11 (B): the reference's block-mixture proposal
+def test_g13_changepoint_block_proposal_vs_reference_fixture(ra):
+    from riemann_amd.proposals import ChangepointRegression1DProp
+    z = load("g13_changepoint_block")
+    m = cp_model(z)
+    p = ChangepointRegression1DProp(m, float(z["hscale"]))
+    assert (p.P_cumprop_cpx, p.P_cumprop_cpv, p.P_cumprop_sig, p.P_cumprop_dim) == (0.2, 0.4, 0.6, 1.0)
+    np.testing.assert_allclose(np.diag(p.L) ** 2, z["Cdiag"], rtol=1e-14)
+    p.P_cumprop_cpv = 1.0        # as the fixture: cpx with 0.2, else cpv
+    s = ra.Sampler(m, p, z["theta0"], seed=int(z["seed"]))
+    s.run(160)
+    check_run(z, s)
+
+
+def test_changepoint_block_proposal_many_chains_vs_oracle(ra, orc):
+    """Default probabilities (0.2 / 0.32 / 0.288, else the null move) on 4096 chains."""
+    from riemann_amd.proposals import ChangepointRegression1DProp
+    from riemann_amd import workloads as W
+    x, y, truth, cdiag = W.changepoint_data()
+    k, d, N, T = 5, 12, 4096, 60
+    from riemann_amd.models import ChangepointRegression1D
+    m = ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=k)
+    p = ChangepointRegression1DProp(m, 2.0)
+    p.scale = 0.5
+    g = np.random.default_rng(8)
+    th0 = truth + 0.01 * g.standard_normal((N, d))
+    th0[:, :k] = np.sort(th0[:, :k], axis=1)
+    s = ra.Sampler(m, p, th0, seed=21, chain0=77)
+    s.run(T)
+    om = orc.Changepoint(x, y, k, 1.0, 3.0, 5.0, 1.0, 1.0)
+    op = orc.BlockRandomWalk(np.diag(np.diag(p.L) ** 2), [k, k + 1, 1], [0.2, 0.4, 0.6], scale=0.5)
+    th = th0.copy()
+    st = orc.rng_seed(21, N, chain0=77)
+    lp = om.log_posterior(th)
+    ht, hl, acc = orc.run(om, op, th, lp, st, T)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(s._chain_logpost, hl, rtol=RTOL)
+    moved = np.diff(s._chain_thetas, axis=0) != 0
+    nblocks = moved[:, :, :k].any(-1).astype(int) + moved[:, :, k:2 * k + 1].any(-1) + moved[:, :, -1]
+    assert nblocks.max() == 1 and moved[:, :, -1].any() and moved[:, :, :k].any()
+    # the plain full-vector walk is still available from the same object
+    from riemann_amd import _lib
+    with pytest.raises(ra.ParameterError):
+        _lib.call("rmh_proposal_rw_set_blocks", p._h, 2, np.array([5, 6], dtype=np.int32), _lib.as_f64([0.5, 1.0]))

@@ -326,3 +326,36 @@ def test_g12_parallel_tempering():
     check_pt(z, *pt_replay(z, orc.Gaussian(z["mu"], z["C"])))
     z = load("g12_pt_mix2d")
     check_pt(z, *pt_replay(z, orc.Mixture(MIX2D)))
+
+
+def test_g13_changepoint_block_proposal():
+    """a-11 variant (B): the reference's ChangepointRegression1DProp at fixed k."""
+    z = load("g13_changepoint_block")
+    model = cp_model(z)
+    prop = orc.BlockRandomWalk(np.diag(z["Cdiag"]), z["sizes"], z["pcum"])
+    check_run(z, *replay(z, model, prop))
+    # which block moved: only the picked block's coordinates differ between proposal and state
+    k = int(z["k"])
+    moved = np.diff(z["thetas"], axis=0) != 0
+    acc = z["accept"].astype(bool)
+    assert (moved[:, :, :k].any(-1) == (acc & (z["picked"] == 0))).all()
+    assert (moved[:, :, k:2 * k + 1].any(-1) == (acc & (z["picked"] == 1))).all()
+    assert not moved[:, :, -1].any()
+
+
+def test_block_proposal_null_move_and_sig_block():
+    """Blocks the reference cannot record here: sig (P = 1 after two failures) and the
+    no-block case (the proposal is theta itself, always accepted, nothing changes)."""
+    z = load("g13_changepoint_block")
+    model = cp_model(z)
+    k = int(z["k"])
+    th = np.ascontiguousarray(z["theta0"]).copy()
+    st = orc.rng_seed(7, th.shape[0])
+    lp = model.log_posterior(th)
+    prop = orc.BlockRandomWalk(np.diag(z["Cdiag"]), z["sizes"], [0.0, 0.0, 1.0], scale=0.3)
+    ht, _, acc = orc.run(model, prop, th, lp, st, 50)
+    moved = np.diff(ht, axis=0) != 0
+    assert not moved[:, :, :2 * k + 1].any() and moved[:, :, -1].any()
+    prop0 = orc.BlockRandomWalk(np.diag(z["Cdiag"]), z["sizes"], [0.0, 0.0, 0.0])
+    ht, _, acc = orc.run(model, prop0, th, lp, st, 20)
+    assert acc.all() and not (np.diff(ht, axis=0) != 0).any()

@@ -1148,8 +1148,8 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
     if (K > 0) { // parallel tempering: the slots' inverse temperatures
         if (p->kind != kRW || adapt)
             return fail(RMH_ERR_PARAM, "run_pt: built for MetropolisRandomWalk within-chain moves only");
-        if (m->kind != kGauss && m->kind != kMixture)
-            return fail(RMH_ERR_PARAM, "run_pt: built for the Gaussian and mixture models only");
+        if (m->kind == kChangepoint)
+            return fail(RMH_ERR_PARAM, "run_pt: not built for the changepoint kernel");
         std::vector<double> b((size_t)s->ld, 1.0);
         const int used = (16 / K) * K;
         for (int64_t c0 = 0; c0 < s->ld; ++c0)
@@ -1164,8 +1164,9 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
     hipError_t e = hipSuccess;
     if (K > 0) {
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
-        e = m->kind == kGauss ? launch_gauss_pt(m->NT, m->ga, ra, c, r, g_stream)
-                              : launch_mix_rw(m->NT, m->ma, ra, c, r, g_stream);
+        e = m->kind == kGauss    ? launch_gauss_pt(m->NT, m->ga, ra, c, r, g_stream)
+            : m->kind == kLogReg ? launch_logreg_rw(m->NT, m->la, ra, c, r, false, g_stream)
+                                 : launch_mix_rw(m->NT, m->ma, ra, c, r, g_stream);
     } else if (p->kind == kPCN) {
         RwArgs ra{p->d_Ltiles, p->d_V, p->rho};
         if (m->kind != kGauss) return fail(RMH_ERR_PARAM, "run: pCN is built for the Gaussian model only");
@@ -1186,7 +1187,7 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         else if (m->kind == kChangepoint) e = launch_cp_rw(m->k, m->ca, ra, c, r, g_stream);
         else if (m->kind == kMixture && !adapt) e = launch_mix_rw(m->NT, m->ma, ra, c, r, g_stream);
         else if (m->kind == kMixture) return fail(RMH_ERR_PARAM, "run: scale adaptation is not built for the mixture model");
-        else return fail(RMH_ERR_PARAM, "run: random walk on the logistic model is not built yet");
+        else e = launch_logreg_rw(m->NT, m->la, ra, c, r, adapt, g_stream);
     } else {
         HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT};
         if (m->kind == kMixture) return fail(RMH_ERR_PARAM, "hmc: MixtureDist has no gradient");

@@ -134,6 +134,8 @@ hipError_t launch_gauss_propose_hmc(int NT, const GaussArgs &m, const HmcArgs &p
 hipError_t launch_logreg_eval(int NT, const LogRegArgs &m, const ChainArgs &c, int want_grad,
                               double *lp_out, double *grad_out, double *lprior_out,
                               double *llik_out, hipStream_t st);
+hipError_t launch_logreg_rw(int NT, const LogRegArgs &m, const RwArgs &p, const ChainArgs &c,
+                            const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, const ChainArgs &c,
                              const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_logreg_propose_hmc(int NT, const LogRegArgs &m, const HmcArgs &p,

@@ -157,6 +157,22 @@ hipError_t launch_logreg_eval(int NT, const LogRegArgs &m, const ChainArgs &c, i
     })
 }
 
+// random walk (plain, AdaptScale, or parallel tempering) on the logistic model: the
+// proposal's tile image stays in global memory, the LDS belongs to the X stages
+hipError_t launch_logreg_rw(int NT, const LogRegArgs &m, const RwArgs &p, const ChainArgs &c,
+                            const RunArgs &r, bool adapt, hipStream_t st)
+{
+    RMH_NT_DISPATCH(NT, {
+        using M = LogRegModel<kNT>;
+        const size_t lds = sizeof(double) * (M::lds_doubles(false) + kIcdfDoubles);
+        if (r.pt_K > 0)
+            return launch(k_run_rw<M, 4, false, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
+        if (adapt)
+            return launch(k_run_rw<M, 4, true, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
+        return launch(k_run_rw<M, 4, false, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
+    })
+}
+
 hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, const ChainArgs &c,
                              const RunArgs &r, bool adapt, hipStream_t st)
 {

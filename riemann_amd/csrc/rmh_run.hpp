@@ -94,16 +94,19 @@ struct AdaptScale {
 // sequential "already swapped" rule (:104-106) is resolved per ensemble from one
 // ballot.  An accepted swap exchanges the two replicas' registers with ds_bpermute
 // (neighbouring lanes of the same 16-lane row): no memory traffic.
-template <class M, int NW, bool ADAPT, bool PCN = false, bool PT = false>
+// LGLOBAL: the proposal's tile image is read from global memory (L2) instead of LDS
+// (models whose own LDS use leaves no room for it: the logistic regression).
+template <class M, int NW, bool ADAPT, bool PCN = false, bool PT = false, bool LGLOBAL = false>
 __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
     using T = Tile<NT>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *Limg = lds;
-    double *mlds = lds + tri_tiles(NT) * 64;
+    const double *Limg = LGLOBAL ? pr.Ltiles : lds;
+    double *mlds = lds + (LGLOBAL ? 0 : tri_tiles(NT) * 64);
     double *tab = mlds + M::lds_doubles(false);
-    for (int i = threadIdx.x; i < tri_tiles(NT) * 64; i += blockDim.x) Limg[i] = pr.Ltiles[i];
+    if (!LGLOBAL)
+        for (int i = threadIdx.x; i < tri_tiles(NT) * 64; i += blockDim.x) lds[i] = pr.Ltiles[i];
     M::setup(mlds, m, false);
     icdf_stage(tab, ch.icdf);
     __syncthreads();
@@ -174,7 +177,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
 #pragma unroll
             for (int s = 0; s < S; ++s) thp[s] = pr.rho * th[s];
             T::pack(thp, acc);
-            T::mul_lower(Limg + lane, xi, acc, ch.ks);   // image holds rho_c * L
+            T::template mul_lower<LGLOBAL>(Limg + lane, xi, acc, ch.ks);   // image holds rho_c * L
             T::unpack(acc, thp);
             double ufw[S], urv[S];
 #pragma unroll
@@ -194,13 +197,13 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
         } else if (ADAPT) { // the chain's own adapted scale: theta + scale * (L xi), image unscaled
 #pragma unroll
             for (int i = 0; i < NT; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
-            T::mul_lower(Limg + lane, xi, acc, ch.ks);
+            T::template mul_lower<LGLOBAL>(Limg + lane, xi, acc, ch.ks);
             T::unpack(acc, thp);
 #pragma unroll
             for (int s = 0; s < S; ++s) thp[s] = th[s] + ad.scale * thp[s];
         } else {
             T::pack(th, acc);
-            T::mul_lower(Limg + lane, xi, acc, ch.ks);
+            T::template mul_lower<LGLOBAL>(Limg + lane, xi, acc, ch.ks);
             T::unpack(acc, thp);
         }
         M::template eval<false>(mlds, m, false, lane, thp, lpp, dummy, parts);

@@ -825,3 +825,48 @@ def test_changepoint_block_proposal_many_chains_vs_oracle(ra, orc):
     from riemann_amd import _lib
     with pytest.raises(ra.ParameterError):
         _lib.call("rmh_proposal_rw_set_blocks", p._h, 2, np.array([5, 6], dtype=np.int32), _lib.as_f64([0.5, 1.0]))
+
+
+# ------------------------------------------- random walk on the logistic model
+@pytest.mark.parametrize("n,d", [(2000, 100), (300, 16)])
+def test_logreg_random_walk_plain_adaptive_and_tempered(ra, orc, n, d):
+    from riemann_amd.models import LogisticRegression
+    from riemann_amd.proposals import AdaptScaleRandomWalk, MetropolisRandomWalk
+    from riemann_amd.samplers import PTSampler
+    from riemann_amd.workloads import logreg_data
+    X, y = logreg_data(n, d, seed=4)
+    g = np.random.default_rng(n + d)
+    th0 = 0.05 * g.standard_normal((200, d))
+    A = g.standard_normal((d, d))
+    Cp = (0.02 / d) * (A @ A.T / d + np.eye(d))
+    m, om = LogisticRegression(X, y, 100.0), orc.LogReg(X, y, 100.0)
+    T = 14
+    s = ra.Sampler(m, MetropolisRandomWalk(Cp), th0, seed=3)
+    s.run(T)
+    ht, hl, acc = oracle_run(orc, om, orc.RandomWalk(Cp), th0, 3, T)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(s._chain_logpost, hl, rtol=RTOL)
+    assert 0.05 < acc.mean() < 0.95
+    # AdaptScaleRandomWalk (randomwalk.py:29-38)
+    s = ra.Sampler(m, AdaptScaleRandomWalk(Cp), th0, seed=4)
+    s.run(T)
+    th = np.ascontiguousarray(th0).copy()
+    st = orc.rng_seed(4, th.shape[0])
+    ad = orc.new_adapt_state(th.shape[0])
+    ht, hl, acc = orc.run(om, orc.set_adapt(orc.RandomWalk(Cp), 0.25), th, om.log_posterior(th), st, T, adapt=ad)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    # PTSampler over TemperedModel(logistic): the prior is not tempered (ptsampler.py:38-39)
+    K, betas = 4, 0.5 ** np.arange(4)
+    pt = PTSampler(m, MetropolisRandomWalk(Cp), th0[:60], betas=betas, Pswap=0.3, seed=5)
+    pt.run(T)
+    S, idx = orc.pt_slots(60, K)
+    slots = np.zeros((S, d))
+    slots[:] = th0[0]
+    slots[idx] = th0[:60, None, :]
+    st = orc.rng_seed(5, S)
+    ht, hl, code, _ = orc.run_pt(om, orc.RandomWalk(Cp), slots, st, T, betas, 0.3)
+    np.testing.assert_array_equal(pt._host_codes, code[:, idx])
+    np.testing.assert_allclose(pt._host_thetas, ht[:, idx], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(pt._host_logpost, hl[:, idx], rtol=RTOL)

@@ -96,8 +96,8 @@ int rmh_proposal_rw_create(const double *L, int d, double scale, rmh_proposal_t 
  * trans-dimensional branch (:56-71), which does not exist at fixed k: theta' = theta.
  * nblk = 0 returns to the full-vector random walk.  (Changepoint model, fused run only.) */
 int rmh_proposal_rw_set_blocks(rmh_proposal_t p, int nblk, const int *sizes, const double *pcum);
-/* pCN(C, rho), proposals/randomwalk.py:78-101.  L = cholesky(C).  (Gaussian model,
- * fused run only.) */
+/* pCN(C, rho), proposals/randomwalk.py:78-101.  L = cholesky(C).  (Fused run only;
+ * Gaussian, mixture and logistic models.) */
 int rmh_proposal_pcn_create(const double *L, int d, double rho, rmh_proposal_t *out);
 /* VanillaHMC(eps, Nsteps, gradlogpost, M=None), proposals/hamiltonian.py:60-91;
  * the gradient is the device Model's.  Nsteps = 1 is MALA. */

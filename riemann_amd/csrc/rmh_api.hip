@@ -1166,12 +1166,14 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
         e = m->kind == kGauss    ? launch_gauss_pt(m->NT, m->ga, ra, c, r, g_stream)
             : m->kind == kLogReg ? launch_logreg_rw(m->NT, m->la, ra, c, r, false, g_stream)
-                                 : launch_mix_rw(m->NT, m->ma, ra, c, r, g_stream);
+                                 : launch_mix_rw(m->NT, m->ma, ra, c, r, false, g_stream);
     } else if (p->kind == kPCN) {
         RwArgs ra{p->d_Ltiles, p->d_V, p->rho};
-        if (m->kind != kGauss) return fail(RMH_ERR_PARAM, "run: pCN is built for the Gaussian model only");
+        if (m->kind == kChangepoint) return fail(RMH_ERR_PARAM, "run: pCN is not built for the changepoint kernel");
         if (adapt) return fail(RMH_ERR_PARAM, "run: AdaptScalepCN is not built");
-        e = launch_gauss_pcn(m->NT, m->ga, ra, c, r, g_stream);
+        e = m->kind == kGauss    ? launch_gauss_pcn(m->NT, m->ga, ra, c, r, g_stream)
+            : m->kind == kLogReg ? launch_logreg_pcn(m->NT, m->la, ra, c, r, g_stream)
+                                 : launch_mix_pcn(m->NT, m->ma, ra, c, r, g_stream);
     } else if (p->kind == kRW) {
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
         if (p->nblk > 0) {
@@ -1185,8 +1187,7 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         }
         if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
         else if (m->kind == kChangepoint) e = launch_cp_rw(m->k, m->ca, ra, c, r, g_stream);
-        else if (m->kind == kMixture && !adapt) e = launch_mix_rw(m->NT, m->ma, ra, c, r, g_stream);
-        else if (m->kind == kMixture) return fail(RMH_ERR_PARAM, "run: scale adaptation is not built for the mixture model");
+        else if (m->kind == kMixture) e = launch_mix_rw(m->NT, m->ma, ra, c, r, adapt, g_stream);
         else e = launch_logreg_rw(m->NT, m->la, ra, c, r, adapt, g_stream);
     } else {
         HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT};

@@ -870,3 +870,34 @@ def test_logreg_random_walk_plain_adaptive_and_tempered(ra, orc, n, d):
     np.testing.assert_array_equal(pt._host_codes, code[:, idx])
     np.testing.assert_allclose(pt._host_thetas, ht[:, idx], rtol=RTOL, atol=1e-12)
     np.testing.assert_allclose(pt._host_logpost, hl[:, idx], rtol=RTOL)
+
+
+def test_pcn_and_adaptive_scale_on_mixture_and_logistic(ra, orc):
+    """The remaining model x proposal cells of the random-walk family, against the oracle."""
+    from riemann_amd.models import LogisticRegression, benchmarks as b
+    from riemann_amd.proposals import AdaptScaleRandomWalk, pCN
+    from riemann_amd.workloads import logreg_data
+    T = 40
+    th0 = np.random.default_rng(2).standard_normal((300, 2))
+    om = orc.Mixture(MIX2D)
+    s = ra.Sampler(b.benchmark_gauss2d_mix2_cross, pCN(np.eye(2), 0.8), th0, seed=6)
+    s.run(T)
+    ht, hl, acc = oracle_run(orc, om, orc.PCN(np.eye(2), 0.8), th0, 6, T)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    s = ra.Sampler(b.benchmark_gauss2d_mix2_cross, AdaptScaleRandomWalk(np.eye(2)), th0, seed=7)
+    s.run(T)
+    th, st, ad = th0.copy(), orc.rng_seed(7, 300), orc.new_adapt_state(300)
+    ht, hl, acc = orc.run(om, orc.set_adapt(orc.RandomWalk(np.eye(2)), 0.25), th, om.log_posterior(th), st, T, adapt=ad)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    X, y = logreg_data(500, 40, seed=9)
+    m, ol = LogisticRegression(X, y, 100.0), orc.LogReg(X, y, 100.0)
+    th0 = 0.05 * np.random.default_rng(3).standard_normal((200, 40))
+    Cp = 0.05 * np.eye(40)
+    s = ra.Sampler(m, pCN(Cp, 0.98), th0, seed=8)
+    s.run(12)
+    ht, hl, acc = oracle_run(orc, ol, orc.PCN(Cp, 0.98), th0, 8, 12)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(s._chain_logpost, hl, rtol=RTOL)

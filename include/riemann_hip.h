@@ -113,6 +113,27 @@ int rmh_proposal_set_eps(rmh_proposal_t p, double eps);     /* .eps, hamiltonian
  * adaptive variant; the per-chain state [Nsamples, Naccepts, scale] lives with the
  * chains (rmh_state_get_adapt / rmh_state_set_adapt, (N,3) float64). */
 int rmh_proposal_set_adapt(rmh_proposal_t p, double target_accept_rate);
+/* AdaptCovProposal mix-in (Haario et al. 2001), proposals/adaptive.py:38-103, as
+ * AdaptCovRandomWalk (randomwalk.py:41-56): the proposal covariance follows the covariance of
+ * the chain history.  The reference adapts one chain's proposal from that chain; here ONE
+ * proposal serves all chains of the run and the accumulators S, SX, SX2 of adapt()
+ * (:73-76) are pooled over chains (and over ranks when rmh_comm_init was called: one
+ * all-reduce per update) -- for one chain this is the reference's algorithm.  Updates
+ * happen after the n-th step of every chain when `np.sqrt(n)**2 == n and n > 2` (:81-82)
+ * evaluates true in double arithmetic, which besides the perfect squares it is meant to
+ * select also holds for about half of the other n; exact_squares != 0 restricts updates to
+ * perfect squares.  C0 (d,d) initial covariance (NULL switches the adaptation off); t_adapt,
+ * marginalize, smooth_adapt as at :45-58.  `C = C0 if n < t_adapt` does what :90 says
+ * (the reference stores it in an unused variable).  d <= 111; plain random walk on the
+ * Gaussian, mixture and logistic models.  rmh_run then issues one launch per stretch
+ * between updates. */
+int rmh_proposal_set_adapt_cov(rmh_proposal_t p, const double *C0, double t_adapt, int marginalize,
+                               int smooth_adapt, int exact_squares);
+/* adaptation state for checkpoints: [n, SX (d), SX2 (d,d), C (d,d), L (d,d)] (this rank's
+ * sums; C, L the current proposal covariance and factor, self.C / self.L of :99-102);
+ * `count` = samples in the sums (chains x n) */
+int rmh_proposal_adapt_cov_get(rmh_proposal_t p, double *st);
+int rmh_proposal_adapt_cov_set(rmh_proposal_t p, const double *st, double count);
 int rmh_proposal_free(rmh_proposal_t p);
 
 /* Proposal.propose (proposal.py:10-17) for N states: theta (N,d) ->

@@ -80,6 +80,9 @@ def lib():
     L.orc_run_pt.restype = i32
     L.orc_run_pt.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, _f64p, i32, dbl, vp, vp, vp]
     L.orc_proposal_set_blocks.argtypes = [vp, i32, _i32p, _f64p]
+    L.orc_run_adaptcov.restype = i32
+    L.orc_run_adaptcov.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, _f64p, _f64p, dbl, i32, i32,
+                                   i32, vp, vp, vp]
     L.orc_max_threads.restype = i32
     _lib = L
     return L
@@ -308,6 +311,42 @@ def run(model, proposal, theta, logpost, rng_state, T, history=True, nthreads=0,
                              adapt.ctypes.data if adapt is not None else None)
     if rc != 0:
         raise ValueError("oracle: model and proposal dimensions differ")
+    return ht, hl, acc
+
+
+def new_adaptcov_state(C0):
+    """[n, SX, SX2, C, L] of AdaptCovProposal.__init__ (proposals/adaptive.py:59-67)."""
+    C0 = _c(np.atleast_2d(C0))
+    d = C0.shape[0]
+    st = np.zeros(1 + d + 3 * d * d)
+    st[1 + d + d * d:1 + d + 2 * d * d] = C0.ravel()
+    st[1 + d + 2 * d * d:] = np.linalg.cholesky(C0).ravel()
+    return st
+
+
+def adaptcov_CL(st, d):
+    """The adapted (C, L) held in an adaptcov state vector."""
+    o = 1 + d + d * d
+    return st[o:o + d * d].reshape(d, d).copy(), st[o + d * d:].reshape(d, d).copy()
+
+
+def run_adaptcov(model, proposal, theta, logpost, rng_state, T, st, C0, t_adapt=1,
+                 marginalize=False, smooth_adapt=False, history=True, exact_squares=False):
+    """Sampler.run with AdaptCovRandomWalk pooled over the N chains
+    (/root/reference/riemann/proposals/adaptive.py:38-103).  ``proposal`` is a RandomWalk
+    (its scale is used; its L is replaced by the adapted one in ``st``)."""
+    N, d = theta.shape
+    ht = np.empty((T + 1, N, d)) if history else None
+    hl = np.empty((T + 1, N)) if history else None
+    acc = np.empty((T, N), dtype=np.uint8)
+    rc = lib().orc_run_adaptcov(model._h, proposal._h, N, theta, logpost, rng_state, T, st,
+                                _c(np.atleast_2d(C0)), float(t_adapt), int(marginalize),
+                                int(smooth_adapt), int(exact_squares), ht.ctypes.data if history else None,
+                                hl.ctypes.data if history else None, acc.ctypes.data)
+    if rc == -2:
+        raise np.linalg.LinAlgError("adapted covariance is not positive definite")
+    if rc != 0:
+        raise ValueError("oracle: bad AdaptCov arguments")
     return ht, hl, acc
 
 

@@ -781,6 +781,128 @@ int orc_run_adapt(const orc_model *m, const orc_proposal *p, int64_t N, double *
 }
 
 /* ------------------------------------------------------------------------- */
+/* 4b. AdaptCovRandomWalk (Haario et al. 2001): proposals/adaptive.py:38-103,    */
+/*     proposals/randomwalk.py:41-56, POOLED over the N chains                  */
+/* ------------------------------------------------------------------------- */
+/*
+ * The reference adapts the proposal of ONE chain from that chain's history:
+ * adapt(theta) (sampler.py:88) after every step accumulates S += 1, SX += theta,
+ * SX2 += theta theta^T (adaptive.py:73-76) and, when n = S is a perfect square > 2
+ * (:81-82), sets
+ * -- in fact whenever the float test np.sqrt(n)**2 == n passes, see the run loop --
+ *   Cs = (SX2 - SX SX^T / n) / (n - 1)                                     :83
+ *   smooth_adapt:  C = (n Cs + t_adapt C0) / (n + t_adapt)                 :86
+ *   else        :  C = C0 if n < t_adapt                (:90 stores it in a dead
+ *                      variable `_cov`; this restatement does what it says)
+ *                  C = Cs + 1e-12 mean(diag C0) I  otherwise              :92-93
+ *   marginalize :  C = diag(diag C)                                        :96-97
+ *   C /= d^0.4;  L = cholesky(C) / d^0.2                                   :101-102
+ * With N chains the build keeps ONE proposal for all of them and pools the
+ * accumulators over chains: after iteration n of every chain the
+ * sample count is N n, the update schedule stays "n a perfect square > 2", and
+ * `n` in the three formulas above is the pooled count N n.  For N = 1 this is the
+ * reference's algorithm (np.float, removed from numpy, read as float; :81).
+ *
+ * st: [n, SX (d), SX2 (d*d), C (d*d), L (d*d)] updated in place; on the first call
+ * n = 0, sums 0, C = C0, L = cholesky(C0) (adaptive.py:59-67).  p supplies .scale.
+ * Returns 0, -1 on a dimension mismatch, -2 if a covariance is not positive definite
+ * (the reference raises LinAlgError there).
+ */
+static int orc_cholesky(const double *C, int d, double *L)
+{
+    memset(L, 0, sizeof(double) * d * d);
+    for (int j = 0; j < d; j++) {
+        double s = C[j * d + j];
+        for (int k = 0; k < j; k++) s -= L[j * d + k] * L[j * d + k];
+        if (!(s > 0.0)) return -2;
+        const double ljj = sqrt(s);
+        L[j * d + j] = ljj;
+        for (int i = j + 1; i < d; i++) {
+            double t = C[i * d + j];
+            for (int k = 0; k < j; k++) t -= L[i * d + k] * L[j * d + k];
+            L[i * d + j] = t / ljj;
+        }
+    }
+    return 0;
+}
+
+int orc_adaptcov_update(double *st, const double *C0, int d, double ntot, double t_adapt,
+                        int marginalize, int smooth)
+{
+    double *SX = st + 1, *SX2 = SX + d, *C = SX2 + (size_t)d * d, *L = C + (size_t)d * d;
+    double tr = 0;
+    for (int i = 0; i < d; i++) tr += C0[i * d + i];
+    const double creg = 1e-12 * (tr / d);
+    for (int i = 0; i < d; i++)
+        for (int j = 0; j < d; j++) {
+            const double cs = (SX2[i * d + j] - SX[i] * SX[j] / ntot) / (ntot - 1);
+            double c;
+            if (smooth) c = (ntot * cs + t_adapt * C0[i * d + j]) / (ntot + t_adapt);
+            else if (ntot < t_adapt) c = C0[i * d + j];
+            else c = cs + (i == j ? creg : 0.0);
+            if (marginalize && i != j) c = 0.0;
+            C[i * d + j] = c / pow((double)d, 0.4);
+        }
+    const int rc = orc_cholesky(C, d, L);
+    if (rc) return rc;
+    const double f = pow((double)d, 0.2);
+    for (int i = 0; i < d * d; i++) L[i] /= f;
+    return 0;
+}
+
+int orc_run_adaptcov(const orc_model *m, const orc_proposal *p, int64_t N, double *theta,
+                     double *logpost, u64 *rng, int T, double *st, const double *C0,
+                     double t_adapt, int marginalize, int smooth, int exact_squares,
+                     double *hist_theta, double *hist_logpost, uint8_t *accept)
+{
+    const int d = m->d;
+    if (p->d != d || p->kind != ORC_RW) return -1;
+    double *SX = st + 1, *SX2 = SX + d, *L = SX2 + 2 * (size_t)d * d;
+    double *work = (double *)malloc(sizeof(double) * d * 6);
+    double *xi = work, *thp = work + d, *w2 = work + 2 * d;
+    orc_proposal q = *p;
+    q.L = L;
+    q.nblk = 0;
+    if (hist_theta) memcpy(hist_theta, theta, sizeof(double) * N * d);
+    if (hist_logpost) memcpy(hist_logpost, logpost, sizeof(double) * N);
+    int rc = 0;
+    for (int t = 0; t < T && !rc; t++) {
+        for (int64_t c = 0; c < N; c++) {
+            double *th = theta + c * d;
+            u64 *sc = rng + 16 * c;
+            orc_rng_normals(sc, d, xi);
+            orc_propose1(&q, m, th, xi, thp, w2, 1.0);
+            const double lp_prop = orc_log_post1(m, thp, w2);
+            const double delta = lp_prop - logpost[c] - 0.0;
+            const double mh = (delta < 0) ? delta : 0.0;
+            const int acc = orc_log(orc_rng_uniform(sc)) < mh;
+            if (acc) {
+                memcpy(th, thp, sizeof(double) * d);
+                logpost[c] = lp_prop;
+            }
+            if (accept) accept[(int64_t)t * N + c] = (uint8_t)acc;
+            for (int i = 0; i < d; i++) { /* adapt(), adaptive.py:73-76 */
+                SX[i] += th[i];
+                for (int j = 0; j < d; j++) SX2[i * d + j] += th[i] * th[j];
+            }
+        }
+        st[0] += 1;
+        if (hist_theta) memcpy(hist_theta + (int64_t)(t + 1) * N * d, theta, sizeof(double) * N * d);
+        if (hist_logpost) memcpy(hist_logpost + (int64_t)(t + 1) * N, logpost, sizeof(double) * N);
+        /* :81-82 `np.sqrt(n)**2 == n and n > 2`: meant as "n a perfect square", but in
+         * double arithmetic fl(fl(sqrt n)^2) == n also holds for about half of the other n
+         * (11, 14, 17, 21, 22, ...).  The reference's behaviour is the float test, restated
+         * literally; the documented intent is available as the exact_squares variant. */
+        const double n = st[0], r = sqrt(n);
+        const int due = exact_squares ? (floor(r + 0.5) * floor(r + 0.5) == n) : (r * r == n);
+        if (due && n > 2)
+            rc = orc_adaptcov_update(st, C0, d, n * (double)N, t_adapt, marginalize, smooth);
+    }
+    free(work);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
 /* 5. PTSampler.run: samplers/ptsampler.py:42-127                               */
 /* ------------------------------------------------------------------------- */
 /*

@@ -42,6 +42,9 @@ SIGNATURES = {
     "rmh_grad_log_posterior": [_vp, _f64, _i64, _f64],
     "rmh_proposal_rw_create": [_f64, _int, _dbl, _pvp],
     "rmh_proposal_rw_set_blocks": [_vp, _int, _i32, _f64],
+    "rmh_proposal_set_adapt_cov": [_vp, _vp, _dbl, _int, _int, _int],
+    "rmh_proposal_adapt_cov_get": [_vp, _f64],
+    "rmh_proposal_adapt_cov_set": [_vp, _f64, _dbl],
     "rmh_proposal_pcn_create": [_f64, _int, _dbl, _pvp],
     "rmh_proposal_hmc_create": [_dbl, _int, _int, _pvp],
     "rmh_proposal_hmc_set_mass": [_vp, _vp],

@@ -95,6 +95,18 @@ __global__ void k_moments(const double *theta, int64_t N, int64_t ld, int d, dou
 
 } // namespace
 
+namespace rmh {
+int comm_active() { return g_comm != nullptr; }
+// in-place sum over the ranks of a device buffer, on the library's stream
+int comm_allreduce_sum(double *dev, size_t count)
+{
+    if (!g_comm) return comm_fail(RMH_ERR_STATE, "no communicator (rmh_comm_init)");
+    const int r = g_rccl.AllReduce(dev, dev, count, kNcclFloat64, kNcclSum, g_comm, comm_stream());
+    if (r != 0) return comm_fail(RMH_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+    return RMH_OK;
+}
+} // namespace rmh
+
 extern "C" {
 
 int rmh_comm_unique_id(uint8_t *id128)

@@ -151,6 +151,9 @@ hipError_t launch_cp_eval(int k, const CpArgs &m, const ChainArgs &c, double *lp
 hipError_t launch_cp_rw(int k, const CpArgs &m, const RwArgs &p, const ChainArgs &c,
                         const RunArgs &r, hipStream_t st);
 
+// pooled second moments of history entries [e0, e1): see rmh_kernels_mfma.hip
+hipError_t launch_moments(int NT, const double *hist, int64_t e0, int64_t e1, int rows, int64_t ld,
+                          int64_t N, int d, double *partial, int nwg, double *acc, hipStream_t st);
 hipError_t launch_rng_seed(uint64_t *rng, int64_t ld, uint64_t seed, uint64_t chain0,
                            hipStream_t st);
 hipError_t launch_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const double *icdf,

@@ -226,6 +226,102 @@ hipError_t launch_logreg_propose_hmc(int NT, const LogRegArgs &m, const HmcArgs 
     })
 }
 
+// ------------------------------------------------ pooled second moments (AdaptCov)
+// Sum over the states (entries e0..e1-1 of a history block, chains < N) of z z^T with
+// z = (theta, 1): the accumulators S, SX, SX2 of AdaptCovProposal.adapt
+// (riemann/proposals/adaptive.py:73-76) pooled over chains, as ONE symmetric
+// (d+1) x (d+1) product on the matrix cores.  A workgroup stages a panel of 64 chains of
+// one entry in LDS (rows = parameters, padded row stride 66: the (row, chain) gathers of
+// the A/B operands hit 32 distinct even banks per half wave), then every k-block of 4
+// chains feeds v_mfma_f64_16x16x4_f64 with A = Z[tile i], B = Z[tile j]^T -- the two
+// operands have the same lane map, (row l&15, chain l>>4).  The NT(NT+1)/2 lower tile
+// pairs are dealt round-robin to the 4 waves.  Per-workgroup partial sums are written
+// out and added up in a fixed order by k_moments_reduce (reproducible; no atomics).
+constexpr int kMomStride = 66;
+
+template <int NT>
+__global__ void __launch_bounds__(256) k_moments(const double *hist, int64_t e0, int64_t e1, int rows,
+                                                 int64_t ld, int64_t N, int d, double *partial)
+{
+    constexpr int DP = 16 * NT, NTRI = NT * (NT + 1) / 2, TPW = (NTRI + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) double X[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m = lane & 15, k = lane >> 4;
+    int ti[TPW], tj[TPW];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int t = 4 * tt + w;
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= t) ++i;
+        ti[tt] = i;
+        tj[tt] = t - i * (i + 1) / 2;
+    }
+    double4_t acc[TPW];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+    const int64_t ncp = (ld + 63) / 64, npanels = (e1 - e0) * ncp;
+    for (int64_t pid = blockIdx.x; pid < npanels; pid += gridDim.x) {
+        const int64_t e = e0 + pid / ncp, c0 = (pid % ncp) * 64;
+        const double *src = hist + e * (int64_t)rows * ld;
+        for (int idx = tid; idx < DP * 64; idx += 256) {
+            const int row = idx >> 6, col = idx & 63;
+            const int64_t c = c0 + col;
+            double v = 0.0;
+            if (c < N) v = row < d ? src[(int64_t)row * ld + c] : (row == d ? 1.0 : 0.0);
+            X[row * kMomStride + col] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) {
+                if (4 * tt + w < NTRI) {
+                    const double a = X[(16 * ti[tt] + m) * kMomStride + 4 * q + k];
+                    const double b = X[(16 * tj[tt] + m) * kMomStride + 4 * q + k];
+                    acc[tt] = mfma(a, b, acc[tt]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int t = 4 * tt + w;
+        if (t < NTRI) {
+            double *dst = partial + ((int64_t)blockIdx.x * NTRI + t) * 256 + lane;
+            dst[0] = acc[tt].x;
+            dst[64] = acc[tt].y;
+            dst[128] = acc[tt].z;
+            dst[192] = acc[tt].w;
+        }
+    }
+}
+
+__global__ void k_moments_reduce(const double *partial, int nwg, int n, double *acc)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    double s = acc[x];
+    for (int g = 0; g < nwg; ++g) s += partial[(int64_t)g * n + x];
+    acc[x] = s;
+}
+
+// acc (NTRI*256 doubles, tile-pair order) += moments of hist entries [e0, e1)
+hipError_t launch_moments(int NT, const double *hist, int64_t e0, int64_t e1, int rows, int64_t ld,
+                          int64_t N, int d, double *partial, int nwg, double *acc, hipStream_t st)
+{
+    if (e1 <= e0) return hipSuccess;
+    RMH_NT_DISPATCH(NT, {
+        constexpr int NTRI = kNT * (kNT + 1) / 2;
+        const size_t lds = sizeof(double) * 16 * kNT * kMomStride;
+        hipError_t e = launch(k_moments<kNT>, (int64_t)nwg * 4, 4, lds, st, hist, e0, e1, rows, ld, N, d, partial);
+        if (e != hipSuccess) return e;
+        const int n = NTRI * 256;
+        hipLaunchKernelGGL(k_moments_reduce, dim3((n + 255) / 256), dim3(256), 0, st, partial, nwg, n, acc);
+        return hipGetLastError();
+    })
+}
+
 // ------------------------------------------------------------------ utilities
 __global__ void k_rng_seed(uint64_t *rng, int64_t nslots, uint64_t seed, uint64_t chain0)
 {

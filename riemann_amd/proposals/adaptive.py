@@ -1,8 +1,6 @@
-"""Adaptive mix-ins on the device: /root/reference/riemann/proposals/adaptive.py:11-35.
-
-Only the scale adaptation (AdaptScaleProposal) is built so far;
-the Haario covariance adaptation of adaptive.py:38-103 is not (it also needs
-``np.float``, removed from numpy >= 1.24)."""
+"""Adaptive mix-ins on the device: /root/reference/riemann/proposals/adaptive.py:11-103
+(SURVEY.md 8f-1): AdaptScaleProposal (per-chain scale, inside the fused kernel) and
+AdaptCovProposal (Haario covariance adaptation, pooled over the chains)."""
 import numpy as np
 
 from .. import _lib
@@ -43,3 +41,50 @@ class AdaptScaleProposal(DeviceProposal):
     def propose(self, theta):
         raise NotImplementedError("stand-alone propose() of an adaptive proposal is not built: "
                                   "the per-chain scale lives with the Sampler's chains")
+
+
+class AdaptCovProposal(DeviceProposal):
+    """Adapts the proposal covariance to the covariance of the chain history, after
+    Haario et al. (2001) (adaptive.py:38-103).  ``self.C`` and ``self.L`` hold the adapted
+    covariance and its Cholesky factor after ``run``, as in the reference.
+
+    The reference adapts ONE chain's proposal from that chain's history.  Here one
+    proposal serves all N chains of a Sampler and the accumulators of ``adapt`` are pooled
+    over the chains (over the ranks too once ``distributed.cabi_comm_init`` was called); with
+    one chain this is the reference's algorithm.  Two statements of the reference are read
+    as written rather than as executed: ``np.float`` (:81, removed from numpy) is ``float``,
+    and ``C = C0 while n < t_adapt`` is applied (:90 assigns it to an unused ``_cov``).
+    The update test ``np.sqrt(n)**2 == n`` (:82) is kept literally -- in double arithmetic
+    it also passes for about half of the non-squares; ``exact_squares=True`` adapts at
+    perfect squares only (far fewer kernel launches)."""
+
+    def _init_adapt_cov(self, C0, t_adapt=1, marginalize=False, smooth_adapt=False, exact_squares=False):
+        self.C0 = np.array(np.atleast_2d(C0), dtype=np.float64)
+        self.C = self.C0
+        self.L = np.linalg.cholesky(self.C0)
+        self.t_adapt = t_adapt
+        self.marginalize = marginalize
+        self.smooth_adapt = smooth_adapt
+        self.exact_squares = exact_squares
+        self._S = 0.0
+        _lib.call("rmh_proposal_set_adapt_cov", self._h, _lib.as_f64(self.C0).ctypes.data, float(t_adapt),
+                  int(bool(marginalize)), int(bool(smooth_adapt)), int(bool(exact_squares)))
+
+    def _adapt_cov_state(self):
+        d = self.C0.shape[0]
+        st = np.empty(1 + d + 3 * d * d)
+        _lib.call("rmh_proposal_adapt_cov_get", self._h, st)
+        return st
+
+    def _pull_adapt(self, state, single):
+        """Refresh ``C``, ``L`` and the accumulators from the device after a run."""
+        d = self.C0.shape[0]
+        st = self._adapt_cov_state()
+        self._S = st[0]
+        self._SX = st[1:1 + d].copy()
+        self._SX2 = st[1 + d:1 + d + d * d].reshape(d, d).copy()
+        self.C = st[1 + d + d * d:1 + d + 2 * d * d].reshape(d, d).copy()
+        self.L = st[1 + d + 2 * d * d:].reshape(d, d).copy()
+
+    def propose(self, theta):
+        raise NotImplementedError("stand-alone propose() of an adaptive proposal is not built")

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from .. import _lib
-from .adaptive import AdaptScaleProposal
+from .adaptive import AdaptCovProposal, AdaptScaleProposal
 from .proposal import DeviceProposal
 
 
@@ -35,6 +35,21 @@ class AdaptScaleRandomWalk(AdaptScaleProposal, MetropolisRandomWalk):
 
     def _sync(self):
         pass  # the scale is the chains' state, not the proposal's
+
+
+class AdaptCovRandomWalk(AdaptCovProposal, MetropolisRandomWalk):
+    """An adaptive Metropolis random walk after Haario et al. (2001) that updates the
+    proposal shape from the chain covariance (randomwalk.py:41-56); options as in the
+    reference plus ``exact_squares`` (see AdaptCovProposal)."""
+
+    def __init__(self, C0, t_adapt=1, marginalize=False, smooth_adapt=False, exact_squares=False):
+        MetropolisRandomWalk.__init__(self, C0)
+        self._init_adapt_cov(C0, t_adapt=t_adapt, marginalize=marginalize, smooth_adapt=smooth_adapt,
+                             exact_squares=exact_squares)
+
+
+# aliases for backward compatibility, randomwalk.py:59
+AdaptiveMetropolisRandomWalk = HaarioRandomWalk = AdaptCovRandomWalk
 
 
 class pCN(DeviceProposal):

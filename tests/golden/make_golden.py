@@ -542,6 +542,54 @@ def g12_pt():
     save("g12_pt_mix2d", Cprop=1.5 * np.eye(2), **r)
 
 
+def g14_adapt_cov():
+    """AdaptCovRandomWalk (Haario et al. 2001), proposals/adaptive.py:38-103 with
+    randomwalk.py:41-56: strict, smooth_adapt and marginalize variants, one chain each
+    (the reference adapts per chain; the build pools over chains, identical for N = 1).
+    adaptive.py:81 calls ``np.float``, an alias numpy removed in 1.24: it is restored for
+    this run (``np.float = float``, what the alias always was)."""
+    from riemann.proposals.randomwalk import AdaptCovRandomWalk
+    had = hasattr(np, "float")
+    if not had:
+        np.float = float
+    try:
+        m2 = rbench.benchmark_gauss2d_corr
+        C0 = np.array([[0.5, 0.1], [0.1, 0.3]])
+        T = 150
+        for tag, kw in (("strict", {}), ("smooth", dict(t_adapt=20, smooth_adapt=True)),
+                        ("marg", dict(marginalize=True))):
+            outs = []
+            for c in range(3):      # three independent single-chain runs, seeds 140+c
+                r = run_reference(m2, lambda: AdaptCovRandomWalk(C0.copy(), **kw), np.ones((1, 2)) * (c + 1),
+                                  seed=140 + c, T=T,
+                                  capture=lambda p: {"C_final": np.array(p.C), "L_final": np.array(p.L)})
+                outs.append(r)
+            save("g14_adaptcov_%s" % tag, C0=C0, mu=np.zeros(2), C=0.1 * np.eye(2) + 0.9 * np.ones((2, 2)),
+                 t_adapt=np.float64(kw.get("t_adapt", 1)), smooth=np.bool_(kw.get("smooth_adapt", False)),
+                 marginalize=np.bool_(kw.get("marginalize", False)),
+                 seeds=np.array([140, 141, 142], dtype=np.uint64),
+                 theta0=np.stack([o["theta0"][0] for o in outs]),
+                 thetas=np.stack([o["thetas"][:, 0] for o in outs], axis=1),
+                 logpost=np.stack([o["logpost"][:, 0] for o in outs], axis=1),
+                 accept=np.stack([o["accept"][:, 0] for o in outs], axis=1),
+                 C_final=np.stack([o["C_final"][0] for o in outs]),
+                 L_final=np.stack([o["L_final"][0] for o in outs]))
+        # 10-d: the first updates (n = 4, 9) see a rank-deficient sample covariance + 1e-12 ridge
+        d = 10
+        g = np.random.default_rng(14)
+        A = g.standard_normal((d, d))
+        Ct = A @ A.T / d + 0.3 * np.eye(d)
+        m10 = MultiGaussianDist(np.zeros(d), Ct)
+        r = run_reference(m10, lambda: AdaptCovRandomWalk(0.1 * np.eye(d), t_adapt=30, smooth_adapt=True),
+                          g.standard_normal((1, d)), seed=145, T=120,
+                          capture=lambda p: {"C_final": np.array(p.C), "L_final": np.array(p.L)})
+        r.pop("xi")
+        save("g14_adaptcov_10d", Ct=Ct, C0=0.1 * np.eye(d), t_adapt=np.float64(30), **r)
+    finally:
+        if not had:
+            del np.float
+
+
 class BlockReplay:
     """Feeds one chain's draws to the reference's ChangepointRegression1DProp + Sampler:
     the uniforms asked for inside ``propose`` (riemann/test_changepoint.py:47-51) are the
@@ -668,3 +716,4 @@ if __name__ == "__main__":
     g11_mixture()
     g12_pt()
     g13_changepoint_block_proposal()
+    g14_adapt_cov()

@@ -359,3 +359,40 @@ def test_block_proposal_null_move_and_sig_block():
     prop0 = orc.BlockRandomWalk(np.diag(z["Cdiag"]), z["sizes"], [0.0, 0.0, 0.0])
     ht, _, acc = orc.run(model, prop0, th, lp, st, 20)
     assert acc.all() and not (np.diff(ht, axis=0) != 0).any()
+
+
+def _adaptcov_replay(z, model, C0, seed, th0, T):
+    th = np.ascontiguousarray(np.atleast_2d(th0)).copy()
+    st = orc.rng_seed(int(seed), 1)
+    stc = orc.new_adaptcov_state(C0)
+    lp = model.log_posterior(th)
+    ht, hl, acc = orc.run_adaptcov(model, orc.RandomWalk(C0), th, lp, st, T, stc, C0,
+                                   t_adapt=float(z["t_adapt"]),
+                                   marginalize=bool(z["marginalize"]) if "marginalize" in z else False,
+                                   smooth_adapt=bool(z["smooth"]) if "smooth" in z else True)
+    return ht, hl, acc, orc.adaptcov_CL(stc, th.shape[1])
+
+
+@pytest.mark.parametrize("tag", ["strict", "smooth", "marg"])
+def test_g14_adaptive_covariance_random_walk(tag):
+    """AdaptCovRandomWalk of the reference, one chain per run (pooled == per-chain there)."""
+    z = load("g14_adaptcov_" + tag)
+    model = orc.Gaussian(z["mu"], z["C"])
+    T = z["accept"].shape[0]
+    for c in range(3):
+        ht, hl, acc, (Cf, Lf) = _adaptcov_replay(z, model, z["C0"], z["seeds"][c], z["theta0"][c], T)
+        np.testing.assert_array_equal(acc[:, 0], z["accept"][:, c])
+        np.testing.assert_allclose(ht[:, 0], z["thetas"][:, c], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(hl[:, 0], z["logpost"][:, c], rtol=1e-8)
+        np.testing.assert_allclose(Cf, z["C_final"][c], rtol=1e-9, atol=1e-15)
+        np.testing.assert_allclose(Lf, z["L_final"][c], rtol=1e-9, atol=1e-15)
+    assert not np.allclose(z["C_final"][0], z["C0"] / 2 ** 0.4)      # it did adapt
+
+
+def test_g14_adaptive_covariance_10d():
+    z = load("g14_adaptcov_10d")
+    model = orc.Gaussian(np.zeros(10), z["Ct"])
+    ht, hl, acc, (Cf, Lf) = _adaptcov_replay(z, model, z["C0"], z["seed"], z["theta0"], 120)
+    np.testing.assert_array_equal(acc, z["accept"])
+    np.testing.assert_allclose(ht, z["thetas"], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(Lf, z["L_final"][0], rtol=1e-8, atol=1e-14)

@@ -1208,7 +1208,7 @@ int comm_allreduce_sum(double *dev, size_t count);
 
 // ---- AdaptCovProposal, pooled over the chains (proposals/adaptive.py:38-103) -------------
 constexpr int kAcovChunk = 64;   // iterations per launch at most (scratch history size)
-constexpr int kAcovWGs = 256;    // workgroups of the moment kernel
+constexpr int kAcovWGs = 512;    // workgroups of the moment kernel: two per CU (59 KB of LDS each)
 
 static int acov_ntri(const rmh_proposal *p) { return p->acov_NT * (p->acov_NT + 1) / 2; }
 

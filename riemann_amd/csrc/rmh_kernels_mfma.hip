@@ -297,13 +297,23 @@ __global__ void __launch_bounds__(256) k_moments(const double *hist, int64_t e0,
     }
 }
 
-__global__ void k_moments_reduce(const double *partial, int nwg, int n, double *acc)
+// acc[x] += sum_g partial[g][x], g in a fixed order: 16 threads per output each add a
+// strided sixteenth of the partials, then thread 0 of the group adds the 16 in order
+__global__ void __launch_bounds__(256) k_moments_reduce(const double *partial, int nwg, int n, double *acc)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= n) return;
-    double s = acc[x];
-    for (int g = 0; g < nwg; ++g) s += partial[(int64_t)g * n + x];
-    acc[x] = s;
+    __shared__ double part[16][17];
+    const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int x = blockIdx.x * 16 + o;
+    double s = 0.0;
+    if (x < n)
+        for (int g = grp; g < nwg; g += 16) s += partial[(int64_t)g * n + x];
+    part[o][grp] = s;
+    __syncthreads();
+    if (grp == 0 && x < n) {
+        double t = acc[x];
+        for (int g = 0; g < 16; ++g) t += part[o][g];
+        acc[x] = t;
+    }
 }
 
 // acc (NTRI*256 doubles, tile-pair order) += moments of hist entries [e0, e1)
@@ -317,7 +327,7 @@ hipError_t launch_moments(int NT, const double *hist, int64_t e0, int64_t e1, in
         hipError_t e = launch(k_moments<kNT>, (int64_t)nwg * 4, 4, lds, st, hist, e0, e1, rows, ld, N, d, partial);
         if (e != hipSuccess) return e;
         const int n = NTRI * 256;
-        hipLaunchKernelGGL(k_moments_reduce, dim3((n + 255) / 256), dim3(256), 0, st, partial, nwg, n, acc);
+        hipLaunchKernelGGL(k_moments_reduce, dim3((n + 15) / 16), dim3(256), 0, st, partial, nwg, n, acc);
         return hipGetLastError();
     })
 }

@@ -621,8 +621,20 @@ def test_rccl_pooling_entry_points_single_rank(ra):
         assert mom[0] == N
         np.testing.assert_allclose(mom[1:1 + d], th.sum(axis=0), rtol=1e-12, atol=1e-10)
         np.testing.assert_allclose(mom[1 + d:].reshape(d, d), th.T @ th, rtol=1e-12, atol=1e-10)
+        # with a communicator the AdaptCov updates all-reduce their moment sums (one rank: same result)
+        from riemann_amd.proposals import AdaptCovRandomWalk
+        m = MultiGaussianDist(np.zeros(d), np.eye(d))
+        pa = AdaptCovRandomWalk(0.05 * np.eye(d), t_adapt=100, smooth_adapt=True)
+        sa = ra.Sampler(m, pa, th0, seed=3)
+        sa.run(30)
+        with_comm = (sa._chain_thetas.copy(), pa.C.copy())
     finally:
         _lib.call("rmh_comm_destroy")
+    pb = AdaptCovRandomWalk(0.05 * np.eye(d), t_adapt=100, smooth_adapt=True)
+    sb = ra.Sampler(m, pb, th0, seed=3)
+    sb.run(30)
+    np.testing.assert_array_equal(sb._chain_thetas, with_comm[0])
+    np.testing.assert_array_equal(pb.C, with_comm[1])
 
 
 def test_checkpoint_restore_continues_bit_for_bit(ra, tmp_path):

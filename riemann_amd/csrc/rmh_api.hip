@@ -117,6 +117,7 @@ bool lower_ok(const double *L, int d)
 // ------------------------------------------------------------------ handles
 struct rmh_model {
     int kind = 0, d = 0, NT = 0;
+    bool big = false; // 112 < d <= 896: rmh_kernels_big.hip (Gaussian, value only)
     // gaussian
     double *d_W = nullptr, *d_WT = nullptr, *d_mu = nullptr;
     GaussArgs ga{};
@@ -233,6 +234,11 @@ int eval_states(rmh_model *m, const ChainArgs &c, bool want_grad, double *lp, do
     hipError_t e = hipSuccess;
     switch (m->kind) {
     case kGauss:
+        if (m->big) {
+            if (want_grad) return fail(RMH_ERR_PARAM, "gaussian: the gradient is built for d <= 112 only");
+            e = launch_big_gauss_eval(m->NT, m->ga, c, lp, lprior, llik, g_stream);
+            break;
+        }
         e = launch_gauss_eval(m->NT, m->ga, c, want_grad, lp, grad, lprior, llik, g_stream);
         break;
     case kLogReg:
@@ -428,8 +434,9 @@ int rmh_model_gaussian_create(const double *mu, const double *L, int d, rmh_mode
 {
     RMH_NEED_INIT();
     if (d < 1) return fail(RMH_ERR_PARAM, "gaussian: d must be >= 1");
-    const int NT = nt_for_dim(d);
-    if (NT < 0) return fail(RMH_ERR_PARAM, "gaussian: d > 112 is not supported by the MFMA tile yet");
+    const bool big = nt_for_dim(d) < 0;
+    const int NT = big ? nt_big(d) : nt_for_dim(d);
+    if (NT < 0) return fail(RMH_ERR_PARAM, "gaussian: d > 896 is not supported");
     if (!lower_ok(L, d))
         return fail(RMH_ERR_PARAM, "gaussian: L must be a lower-triangular Cholesky factor");
     // W = L^-1 by forward substitution (columns of the identity)
@@ -446,7 +453,10 @@ int rmh_model_gaussian_create(const double *mu, const double *L, int d, rmh_mode
     m->kind = kGauss;
     m->d = d;
     m->NT = NT;
-    std::vector<double> lo = pack_lower(W.data(), d, NT, 1.0), up = pack_upper_T(W.data(), d, NT);
+    m->big = big;
+    std::vector<double> lo = pack_lower(W.data(), d, NT, 1.0), up;
+    if (!big) up = pack_upper_T(W.data(), d, NT);   // gradient image: register-tile kernels only
+    else up.assign(64, 0.0);
     std::vector<double> mup((size_t)16 * NT, 0.0);
     for (int i = 0; i < d; ++i) mup[i] = mu[i];
     int rc;
@@ -661,8 +671,8 @@ int rmh_proposal_rw_create(const double *L, int d, double scale, rmh_proposal_t 
 {
     RMH_NEED_INIT();
     if (d < 1) return fail(RMH_ERR_PARAM, "random walk: d must be >= 1");
-    const int NT = nt_for_dim(d);
-    if (NT < 0) return fail(RMH_ERR_PARAM, "random walk: d > 112 is not supported by the MFMA tile yet");
+    const int NT = nt_for_dim(d) < 0 ? nt_big(d) : nt_for_dim(d);
+    if (NT < 0) return fail(RMH_ERR_PARAM, "random walk: d > 896 is not supported");
     if (!lower_ok(L, d))
         return fail(RMH_ERR_PARAM, "random walk: L must be a lower-triangular Cholesky factor");
     rmh_proposal *p = new rmh_proposal;
@@ -907,6 +917,8 @@ int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
             rc = fail(RMH_ERR_PARAM, "propose: stand-alone pCN proposals are not built");
         } else if (p->kind == kRW && p->nblk > 0) {
             rc = fail(RMH_ERR_PARAM, "propose: stand-alone block-mixture proposals are not built");
+        } else if (p->kind == kRW && p->NT > 7) {
+            rc = fail(RMH_ERR_PARAM, "propose: stand-alone proposals are built for d <= 112");
         } else if (p->kind == kRW) {
             rc = sync_proposal(p);
             if (!rc) {
@@ -1445,7 +1457,12 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
     RMH_HIP(hipEventRecord(g_ev0, g_stream));
     hipError_t e = hipSuccess;
     int launches = 1;
-    if (p->acov) {
+    if (m->big) { // 112 < d <= 896
+        if (p->kind != kRW || adapt || K > 0 || p->acov || p->nblk > 0)
+            return fail(RMH_ERR_PARAM, "run: for d > 112 only the plain random walk on the Gaussian model is built");
+        RwArgs ra{p->d_Ltiles, nullptr, 0.0};
+        e = launch_big_gauss_rw(m->NT, m->ga, ra, c, r, g_stream);
+    } else if (p->acov) {
         if (K > 0 || adapt || p->kind != kRW || p->nblk > 0 || m->kind == kChangepoint)
             return fail(RMH_ERR_PARAM, "run: AdaptCov is built for the plain random walk on the Gaussian, "
                                        "mixture and logistic models");

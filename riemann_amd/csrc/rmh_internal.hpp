@@ -104,6 +104,10 @@ struct HmcArgs {
 // tile counts of the triangular images
 constexpr int tri_tiles(int NT) { return 2 * NT * (NT + 1); }
 inline int nt_for_dim(int d) { return d <= 16 ? 1 : d <= 32 ? 2 : d <= 64 ? 4 : d <= 112 ? 7 : -1; }
+// 112 < d <= 896: the workgroup-per-16-chains kernels of rmh_kernels_big.hip (Gaussian model,
+// random walk): ceil(d/16) tiles, -1 beyond
+constexpr int kBigMaxDim = 896;
+inline int nt_big(int d) { return (d > 112 && d <= kBigMaxDim) ? (d + 15) / 16 : -1; }
 
 // ---- host-side launchers implemented in the kernel files --------------------
 // all return hipError_t of the launch
@@ -154,6 +158,10 @@ hipError_t launch_cp_rw(int k, const CpArgs &m, const RwArgs &p, const ChainArgs
 // pooled second moments of history entries [e0, e1): see rmh_kernels_mfma.hip
 hipError_t launch_moments(int NT, const double *hist, int64_t e0, int64_t e1, int rows, int64_t ld,
                           int64_t N, int d, double *partial, int nwg, double *acc, hipStream_t st);
+hipError_t launch_big_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
+                               const RunArgs &r, hipStream_t st);
+hipError_t launch_big_gauss_eval(int NT, const GaussArgs &m, const ChainArgs &c, double *lp_out,
+                                 double *lprior_out, double *llik_out, hipStream_t st);
 hipError_t launch_rng_seed(uint64_t *rng, int64_t ld, uint64_t seed, uint64_t chain0,
                            hipStream_t st);
 hipError_t launch_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const double *icdf,

@@ -590,6 +590,22 @@ def g14_adapt_cov():
             del np.float
 
 
+def g15_gauss_big_d():
+    """MultiGaussianDist + MetropolisRandomWalk beyond the register-tile size (d = 200):
+    the workgroup-per-16-chains kernels of rmh_kernels_big.hip."""
+    d = 200
+    g = np.random.default_rng(15)
+    A = g.standard_normal((d, d))
+    Ct = A @ A.T / d + 0.2 * np.eye(d)
+    mu = g.standard_normal(d)
+    m = MultiGaussianDist(mu, Ct)
+    Cp = (2.38 ** 2 / d) * Ct
+    th0 = mu + g.standard_normal((3, d)) @ np.linalg.cholesky(Ct).T
+    r = run_reference(m, lambda: MetropolisRandomWalk(Cp), th0, seed=150, T=24)
+    r.pop("xi")
+    save("g15_gauss200d_rw", rng_seed_for_model=np.int64(15), **r)
+
+
 class BlockReplay:
     """Feeds one chain's draws to the reference's ChangepointRegression1DProp + Sampler:
     the uniforms asked for inside ``propose`` (riemann/test_changepoint.py:47-51) are the
@@ -717,3 +733,4 @@ if __name__ == "__main__":
     g12_pt()
     g13_changepoint_block_proposal()
     g14_adapt_cov()
+    g15_gauss_big_d()

@@ -996,3 +996,60 @@ def test_adaptive_covariance_pooled_over_chains_vs_oracle(ra, orc, d, N, squares
     np.testing.assert_array_equal(s2._chain_thetas[5::7], ref_th)
     np.testing.assert_array_equal(p2.C, ref_C)
     assert ref_th.shape[0] == 6
+
+
+# ------------------------------------------------ d > 112: workgroup-per-16-chains kernels
+def test_g15_gauss200d_vs_reference_fixture(ra):
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    z = load("g15_gauss200d_rw")
+    g = np.random.default_rng(15)
+    A = g.standard_normal((200, 200))
+    Ct = A @ A.T / 200 + 0.2 * np.eye(200)
+    mu = g.standard_normal(200)
+    s = ra.Sampler(MultiGaussianDist(mu, Ct), MetropolisRandomWalk((2.38 ** 2 / 200) * Ct), z["theta0"],
+                   seed=int(z["seed"]))
+    s.run(24)
+    check_run(z, s)
+
+
+@pytest.mark.parametrize("d,N", [(113, 50), (128, 33), (257, 16), (500, 40), (896, 17)])
+def test_gauss_random_walk_big_d_vs_oracle(ra, orc, d, N):
+    """Sizes either side of every tile-count bucket of rmh_kernels_big.hip, ragged chain counts,
+    burn/thin/resume bookkeeping, log densities through the eval kernel."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    g = np.random.default_rng(d)
+    A = g.standard_normal((d, d))
+    Ct = A @ A.T / d + 0.2 * np.eye(d)
+    mu = g.standard_normal(d)
+    Cp = (2.38 ** 2 / d) * Ct
+    th0 = mu + g.standard_normal((N, d))
+    m = MultiGaussianDist(mu, Ct)
+    om = orc.Gaussian(mu, Ct)
+    np.testing.assert_allclose(m.log_posterior(th0), om.log_posterior(th0), rtol=RTOL)
+    np.testing.assert_allclose(m.log_likelihood(th0[0]), om.log_likelihood(th0[:1])[0], rtol=RTOL)
+    p = MetropolisRandomWalk(Cp)
+    p.scale = 0.7
+    s = ra.Sampler(m, p, th0, seed=9, chain0=1000)
+    T = 12
+    s.run(T)
+    ht, hl, acc = oracle_run(orc, om, orc.RandomWalk(Cp, 0.7), th0, 9, T, chain0=1000)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(s._chain_logpost, hl, rtol=RTOL)
+    assert 0.02 < acc.mean() < 0.98
+    # continuation with burn-in and thinning == the same chains run straight through
+    s.run(9, 2, 3)
+    ht2, hl2, _ = oracle_run(orc, om, orc.RandomWalk(Cp, 0.7), th0, 9, T + 9, chain0=1000)
+    np.testing.assert_allclose(s._chain_thetas, ht2[T + 2::3], rtol=RTOL, atol=1e-12)
+    th, lp = s.current_state()
+    np.testing.assert_allclose(lp, hl2[T + 8], rtol=RTOL)
+    with pytest.raises(ra.ParameterError):
+        m.grad_log_posterior(th0)
+
+
+def test_dimension_limit_is_reported(ra):
+    from riemann_amd.models import MultiGaussianDist
+    with pytest.raises(ra.ParameterError):
+        MultiGaussianDist(np.zeros(897), np.eye(897))

@@ -396,3 +396,18 @@ def test_g14_adaptive_covariance_10d():
     np.testing.assert_array_equal(acc, z["accept"])
     np.testing.assert_allclose(ht, z["thetas"], rtol=1e-8, atol=1e-12)
     np.testing.assert_allclose(Lf, z["L_final"][0], rtol=1e-8, atol=1e-14)
+
+
+def big_gauss(d=200, seed=15):
+    """The target of fixture G15 (rebuilt from its seed: 320 KB of covariance are not stored)."""
+    g = np.random.default_rng(seed)
+    A = g.standard_normal((d, d))
+    Ct = A @ A.T / d + 0.2 * np.eye(d)
+    mu = g.standard_normal(d)
+    return mu, Ct, (2.38 ** 2 / d) * Ct
+
+
+def test_g15_gauss200d_random_walk():
+    z = load("g15_gauss200d_rw")
+    mu, Ct, Cp = big_gauss()
+    check_run(z, *replay(z, orc.Gaussian(mu, Ct), orc.RandomWalk(Cp)))

@@ -576,8 +576,11 @@ def test_edge_cases_run_lengths_and_sizes(ra, orc):
         ht, hl, acc = oracle_run(orc, orc.Gaussian(np.zeros(d), Cov), orc.RandomWalk(0.1 * Cov), th0, d, 15)
         np.testing.assert_array_equal(s._chain_accept, acc)
         np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    # beyond the largest register tile the logistic model is refused loudly (the Gaussian
+    # random walk continues on the workgroup kernels, tested further down)
+    from riemann_amd.models import LogisticRegression
     with pytest.raises(ra.ParameterError):
-        MultiGaussianDist(np.zeros(113), np.eye(113))   # beyond the largest tile: loud, not wrong
+        LogisticRegression(np.zeros((8, 113)), np.zeros(8), 1.0)
 
 
 def test_non_finite_start_states(ra, orc):

@@ -82,7 +82,7 @@ def lib():
     L.orc_proposal_set_blocks.argtypes = [vp, i32, _i32p, _f64p]
     L.orc_run_adaptcov.restype = i32
     L.orc_run_adaptcov.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, _f64p, _f64p, dbl, i32, i32,
-                                   i32, vp, vp, vp]
+                                   i32, vp, vp, vp, vp]
     L.orc_max_threads.restype = i32
     _lib = L
     return L
@@ -331,7 +331,7 @@ def adaptcov_CL(st, d):
 
 
 def run_adaptcov(model, proposal, theta, logpost, rng_state, T, st, C0, t_adapt=1,
-                 marginalize=False, smooth_adapt=False, history=True, exact_squares=False):
+                 marginalize=False, smooth_adapt=False, history=True, exact_squares=False, adapt=None):
     """Sampler.run with AdaptCovRandomWalk pooled over the N chains
     (/root/reference/riemann/proposals/adaptive.py:38-103).  ``proposal`` is a RandomWalk
     (its scale is used; its L is replaced by the adapted one in ``st``)."""
@@ -342,7 +342,8 @@ def run_adaptcov(model, proposal, theta, logpost, rng_state, T, st, C0, t_adapt=
     rc = lib().orc_run_adaptcov(model._h, proposal._h, N, theta, logpost, rng_state, T, st,
                                 _c(np.atleast_2d(C0)), float(t_adapt), int(marginalize),
                                 int(smooth_adapt), int(exact_squares), ht.ctypes.data if history else None,
-                                hl.ctypes.data if history else None, acc.ctypes.data)
+                                hl.ctypes.data if history else None, acc.ctypes.data,
+                                adapt.ctypes.data if adapt is not None else None)
     if rc == -2:
         raise np.linalg.LinAlgError("adapted covariance is not positive definite")
     if rc != 0:

@@ -853,8 +853,11 @@ int orc_adaptcov_update(double *st, const double *C0, int d, double ntot, double
 int orc_run_adaptcov(const orc_model *m, const orc_proposal *p, int64_t N, double *theta,
                      double *logpost, u64 *rng, int T, double *st, const double *C0,
                      double t_adapt, int marginalize, int smooth, int exact_squares,
-                     double *hist_theta, double *hist_logpost, uint8_t *accept)
+                     double *hist_theta, double *hist_logpost, uint8_t *accept, double *adapt)
 {
+    /* adapt (N,3) non-NULL with p->adapt_target > 0: AdaptScaleCovRandomWalk
+     * (randomwalk.py:62-75): the scale adaptation of adaptive.py:25-35 per chain, then the
+     * covariance adaptation, after every step (:73-75) */
     const int d = m->d;
     if (p->d != d || p->kind != ORC_RW) return -1;
     double *SX = st + 1, *SX2 = SX + d, *L = SX2 + 2 * (size_t)d * d;
@@ -871,7 +874,7 @@ int orc_run_adaptcov(const orc_model *m, const orc_proposal *p, int64_t N, doubl
             double *th = theta + c * d;
             u64 *sc = rng + 16 * c;
             orc_rng_normals(sc, d, xi);
-            orc_propose1(&q, m, th, xi, thp, w2, 1.0);
+            orc_propose1(&q, m, th, xi, thp, w2, adapt ? adapt[3 * c + 2] : 1.0);
             const double lp_prop = orc_log_post1(m, thp, w2);
             const double delta = lp_prop - logpost[c] - 0.0;
             const double mh = (delta < 0) ? delta : 0.0;
@@ -879,6 +882,14 @@ int orc_run_adaptcov(const orc_model *m, const orc_proposal *p, int64_t N, doubl
             if (acc) {
                 memcpy(th, thp, sizeof(double) * d);
                 logpost[c] = lp_prop;
+            }
+            if (adapt && p->adapt_target > 0) { /* adaptive.py:25-35, as in orc_run_adapt */
+                double *a = adapt + 3 * c;
+                const int moved = (a[0] == 0.0) ? 1 : acc;
+                a[0] += 1;
+                a[1] += moved;
+                const double rate = a[1] / a[0], ratio = exp(1.0 / a[0]);
+                if (rate > p->adapt_target) a[2] *= ratio; else a[2] /= ratio;
             }
             if (accept) accept[(int64_t)t * N + c] = (uint8_t)acc;
             for (int i = 0; i < d; i++) { /* adapt(), adaptive.py:73-76 */

@@ -1335,13 +1335,14 @@ static int acov_update(rmh_proposal *p)
     return sync_proposal(p);
 }
 
-static hipError_t launch_rw_plain(rmh_model *m, rmh_proposal *p, const ChainArgs &c, const RunArgs &r)
+// adapt: the AdaptScale variant (per-chain scale in c.adapt, unscaled tile image)
+static hipError_t launch_rw_plain(rmh_model *m, rmh_proposal *p, const ChainArgs &c, const RunArgs &r, bool adapt)
 {
     RwArgs ra{p->d_Ltiles, nullptr, 0.0};
     switch (m->kind) {
-    case kGauss: return launch_gauss_rw(m->NT, m->ga, ra, c, r, false, g_stream);
-    case kMixture: return launch_mix_rw(m->NT, m->ma, ra, c, r, false, g_stream);
-    case kLogReg: return launch_logreg_rw(m->NT, m->la, ra, c, r, false, g_stream);
+    case kGauss: return launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
+    case kMixture: return launch_mix_rw(m->NT, m->ma, ra, c, r, adapt, g_stream);
+    case kLogReg: return launch_logreg_rw(m->NT, m->la, ra, c, r, adapt, g_stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -1377,7 +1378,7 @@ static int run_adaptcov(rmh_model *m, rmh_proposal *p, rmh_state *s, const Chain
         r.h_theta = s->sc_theta;
         r.h_logpost = s->sc_logpost;
         r.h_accept = s->sc_accept;
-        RMH_HIP(launch_rw_plain(m, p, c, r));
+        RMH_HIP(launch_rw_plain(m, p, c, r, c.adapt != nullptr));
         ++*launches;
         if (h) {
             for (int64_t i = (done == 0 ? 0 : 1); i <= seg; ++i) {
@@ -1463,9 +1464,9 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
         e = launch_big_gauss_rw(m->NT, m->ga, ra, c, r, g_stream);
     } else if (p->acov) {
-        if (K > 0 || adapt || p->kind != kRW || p->nblk > 0 || m->kind == kChangepoint)
-            return fail(RMH_ERR_PARAM, "run: AdaptCov is built for the plain random walk on the Gaussian, "
-                                       "mixture and logistic models");
+        if (K > 0 || p->kind != kRW || p->nblk > 0 || m->kind == kChangepoint)
+            return fail(RMH_ERR_PARAM, "run: AdaptCov is built for the random walk (plain or with scale "
+                                       "adaptation) on the Gaussian, mixture and logistic models");
         launches = 0;
         if ((rc = run_adaptcov(m, p, s, c, T, nburn, nthin, h, &launches))) return rc;
     } else if (K > 0) {

@@ -1,11 +1,11 @@
 from .proposal import Proposal, DeviceProposal
 from .adaptive import AdaptScaleProposal, AdaptCovProposal
 from .randomwalk import (MetropolisRandomWalk, AdaptScaleRandomWalk, AdaptCovRandomWalk,
-                         AdaptiveMetropolisRandomWalk, HaarioRandomWalk, pCN)
+                         AdaptScaleCovRandomWalk, AdaptiveMetropolisRandomWalk, HaarioRandomWalk, pCN)
 from .hamiltonian import VanillaHMC, MALA, AdaptScaleHMC
 from .changepoint import ChangepointRegression1DProp
 
 __all__ = ["Proposal", "DeviceProposal", "MetropolisRandomWalk", "VanillaHMC", "MALA",
            "AdaptScaleProposal", "AdaptScaleRandomWalk", "AdaptScaleHMC", "pCN",
-           "ChangepointRegression1DProp", "AdaptCovProposal", "AdaptCovRandomWalk",
+           "ChangepointRegression1DProp", "AdaptCovProposal", "AdaptCovRandomWalk", "AdaptScaleCovRandomWalk",
            "AdaptiveMetropolisRandomWalk", "HaarioRandomWalk"]

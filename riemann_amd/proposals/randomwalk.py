@@ -52,6 +52,25 @@ class AdaptCovRandomWalk(AdaptCovProposal, MetropolisRandomWalk):
 AdaptiveMetropolisRandomWalk = HaarioRandomWalk = AdaptCovRandomWalk
 
 
+class AdaptScaleCovRandomWalk(AdaptScaleProposal, AdaptCovProposal, MetropolisRandomWalk):
+    """A Metropolis random walk that adapts both scale and covariance (randomwalk.py:62-75;
+    "experimental and not obviously correct" there): every chain adapts its own scale
+    towards an acceptance rate of 0.25 while the covariance adapts from the pooled history."""
+
+    def __init__(self, C0, t_adapt=1, marginalize=False, smooth_adapt=False, exact_squares=False):
+        MetropolisRandomWalk.__init__(self, C0)
+        self._init_adapt(0.25)
+        self._init_adapt_cov(C0, t_adapt=t_adapt, marginalize=marginalize, smooth_adapt=smooth_adapt,
+                             exact_squares=exact_squares)
+
+    def _sync(self):
+        pass  # the scale is the chains' state
+
+    def _pull_adapt(self, state, single):
+        AdaptScaleProposal._pull_adapt(self, state, single)
+        AdaptCovProposal._pull_adapt(self, state, single)
+
+
 class pCN(DeviceProposal):
     """A preconditioned Crank-Nicolson proposal (randomwalk.py:78-101):
     theta' = rho theta + sqrt(1-rho^2) L xi with its asymmetric logqratio.

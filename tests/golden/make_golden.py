@@ -585,6 +585,15 @@ def g14_adapt_cov():
                           capture=lambda p: {"C_final": np.array(p.C), "L_final": np.array(p.L)})
         r.pop("xi")
         save("g14_adaptcov_10d", Ct=Ct, C0=0.1 * np.eye(d), t_adapt=np.float64(30), **r)
+        # AdaptScaleCovRandomWalk (randomwalk.py:62-75): scale and covariance adapted together
+        from riemann.proposals.randomwalk import AdaptScaleCovRandomWalk
+        r = run_reference(m10, lambda: AdaptScaleCovRandomWalk(0.1 * np.eye(d), t_adapt=30, smooth_adapt=True),
+                          g.standard_normal((1, d)), seed=146, T=120,
+                          capture=lambda p: {"C_final": np.array(p.C), "L_final": np.array(p.L),
+                                             "scale_final": np.float64(p.scale),
+                                             "Naccepts": np.int64(p.Naccepts)})
+        r.pop("xi")
+        save("g14_adaptscalecov_10d", Ct=Ct, C0=0.1 * np.eye(d), t_adapt=np.float64(30), **r)
     finally:
         if not had:
             del np.float

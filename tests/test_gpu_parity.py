@@ -1056,3 +1056,34 @@ def test_dimension_limit_is_reported(ra):
     from riemann_amd.models import MultiGaussianDist
     with pytest.raises(ra.ParameterError):
         MultiGaussianDist(np.zeros(897), np.eye(897))
+
+
+def test_g14_adaptive_scale_and_covariance_fixture_and_many_chains(ra, orc):
+    """AdaptScaleCovRandomWalk (randomwalk.py:62-75): reference fixture (one chain), then
+    per-chain scales + pooled covariance on many chains against the oracle."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import AdaptScaleCovRandomWalk
+    z = load("g14_adaptscalecov_10d")
+    m = MultiGaussianDist(np.zeros(10), z["Ct"])
+    p = AdaptScaleCovRandomWalk(z["C0"], t_adapt=30, smooth_adapt=True)
+    s = ra.Sampler(m, p, z["theta0"][0], seed=int(z["seed"]))
+    s.run(120)
+    np.testing.assert_array_equal(s._chain_accept, z["accept"][:, 0])
+    np.testing.assert_allclose(s._chain_thetas, z["thetas"][:, 0], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(p.scale, z["scale_final"][0], rtol=1e-12)
+    assert p.Naccepts == z["Naccepts"][0]
+    np.testing.assert_allclose(p.L, z["L_final"][0], rtol=1e-8, atol=1e-14)
+    N, T = 500, 50
+    g = np.random.default_rng(4)
+    th0 = g.standard_normal((N, 10))
+    p = AdaptScaleCovRandomWalk(z["C0"], t_adapt=200, smooth_adapt=True)
+    s = ra.Sampler(m, p, th0, seed=12)
+    s.run(T)
+    om = orc.Gaussian(np.zeros(10), z["Ct"])
+    th, st, stc, ad = th0.copy(), orc.rng_seed(12, N), orc.new_adaptcov_state(z["C0"]), orc.new_adapt_state(N)
+    ht, hl, acc = orc.run_adaptcov(om, orc.set_adapt(orc.RandomWalk(z["C0"]), 0.25), th, om.log_posterior(th),
+                                   st, T, stc, z["C0"], t_adapt=200, smooth_adapt=True, adapt=ad)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(p.scale, ad[:, 2], rtol=1e-12)
+    np.testing.assert_allclose(p.C, orc.adaptcov_CL(stc, 10)[0], rtol=1e-9, atol=1e-15)

@@ -411,3 +411,19 @@ def test_g15_gauss200d_random_walk():
     z = load("g15_gauss200d_rw")
     mu, Ct, Cp = big_gauss()
     check_run(z, *replay(z, orc.Gaussian(mu, Ct), orc.RandomWalk(Cp)))
+
+
+def test_g14_adaptive_scale_and_covariance_10d():
+    """AdaptScaleCovRandomWalk (randomwalk.py:62-75)."""
+    z = load("g14_adaptscalecov_10d")
+    model = orc.Gaussian(np.zeros(10), z["Ct"])
+    th = np.ascontiguousarray(z["theta0"]).copy()
+    st, stc, ad = orc.rng_seed(int(z["seed"]), 1), orc.new_adaptcov_state(z["C0"]), orc.new_adapt_state(1)
+    prop = orc.set_adapt(orc.RandomWalk(z["C0"]), 0.25)
+    ht, hl, acc = orc.run_adaptcov(model, prop, th, model.log_posterior(th), st, 120, stc, z["C0"],
+                                   t_adapt=30, smooth_adapt=True, adapt=ad)
+    np.testing.assert_array_equal(acc, z["accept"])
+    np.testing.assert_allclose(ht, z["thetas"], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(ad[0, 2], z["scale_final"][0], rtol=1e-12)
+    assert ad[0, 1] == z["Naccepts"][0]
+    np.testing.assert_allclose(orc.adaptcov_CL(stc, 10)[1], z["L_final"][0], rtol=1e-8, atol=1e-14)

@@ -124,14 +124,16 @@ int rmh_proposal_set_adapt(rmh_proposal_t p, double target_accept_rate);
  * select also holds for about half of the other n; exact_squares != 0 restricts updates to
  * perfect squares.  C0 (d,d) initial covariance (NULL switches the adaptation off); t_adapt,
  * marginalize, smooth_adapt as at :45-58.  `C = C0 if n < t_adapt` does what :90 says
- * (the reference stores it in an unused variable).  d <= 111; plain random walk on the
- * Gaussian, mixture and logistic models.  rmh_run then issues one launch per stretch
- * between updates. */
+ * (the reference stores it in an unused variable).  d <= 111.  Random-walk proposals (plain,
+ * or with rmh_proposal_set_adapt: AdaptScaleCovRandomWalk, randomwalk.py:62-75) on the
+ * Gaussian, mixture and logistic models; HMC proposals (AdaptCovHMC, hamiltonian.py:107-120:
+ * the adapted C, L become the mass matrix M, chM) on the Gaussian and logistic models.
+ * rmh_run then issues one launch per stretch between updates. */
 int rmh_proposal_set_adapt_cov(rmh_proposal_t p, const double *C0, double t_adapt, int marginalize,
                                int smooth_adapt, int exact_squares);
-/* adaptation state for checkpoints: [n, SX (d), SX2 (d,d), C (d,d), L (d,d)] (this rank's
+/* adaptation state for checkpoints: [n, SX (d), SX2 (d,d), C (d,d), L (d,d), minv] (this rank's
  * sums; C, L the current proposal covariance and factor, self.C / self.L of :99-102);
- * `count` = samples in the sums (chains x n) */
+ * `count` = samples in the sums (chains x n); minv: HMC variant, M^-1 = minv (L L^T)^-1, else 0 */
 int rmh_proposal_adapt_cov_get(rmh_proposal_t p, double *st);
 int rmh_proposal_adapt_cov_set(rmh_proposal_t p, const double *st, double count);
 int rmh_proposal_free(rmh_proposal_t p);

@@ -318,16 +318,16 @@ def new_adaptcov_state(C0):
     """[n, SX, SX2, C, L] of AdaptCovProposal.__init__ (proposals/adaptive.py:59-67)."""
     C0 = _c(np.atleast_2d(C0))
     d = C0.shape[0]
-    st = np.zeros(1 + d + 3 * d * d)
+    st = np.zeros(2 + d + 3 * d * d)
     st[1 + d + d * d:1 + d + 2 * d * d] = C0.ravel()
-    st[1 + d + 2 * d * d:] = np.linalg.cholesky(C0).ravel()
+    st[1 + d + 2 * d * d:1 + d + 3 * d * d] = np.linalg.cholesky(C0).ravel()
     return st
 
 
 def adaptcov_CL(st, d):
     """The adapted (C, L) held in an adaptcov state vector."""
     o = 1 + d + d * d
-    return st[o:o + d * d].reshape(d, d).copy(), st[o + d * d:].reshape(d, d).copy()
+    return st[o:o + d * d].reshape(d, d).copy(), st[o + d * d:o + 2 * d * d].reshape(d, d).copy()
 
 
 def run_adaptcov(model, proposal, theta, logpost, rng_state, T, st, C0, t_adapt=1,

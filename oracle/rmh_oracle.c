@@ -513,6 +513,8 @@ typedef struct orc_proposal {
     int nsteps;
     double adapt_target; /* > 0: AdaptScaleProposal mix-in, proposals/adaptive.py:11-35 */
     double *chM;         /* cholesky(M) when a mass matrix is given, hamiltonian.py:71-74 */
+    double minv;         /* M^-1 = minv (chM chM^T)^-1; 0 reads as 1.  AdaptCovHMC sets M = C and
+                          * chM = L with C = d^0.4 L L^T (hamiltonian.py:117-119 with adaptive.py:101-102) */
     double rho, rho_c;   /* pCN, randomwalk.py:83-87 */
     /* block-mixture random walk, ChangepointRegression1DProp (riemann/test_changepoint.py:18-56) */
     int nblk, blk_end[3];
@@ -645,6 +647,8 @@ static double orc_propose1(const orc_proposal *p, const orc_model *m, const doub
                 for (int j = i + 1; j < d; j++) acc -= C[j * d + i] * (dst)[j];       \
                 (dst)[i] = acc / C[i * d + i];                                        \
             }                                                                         \
+            if (p->minv != 0.0)                                                       \
+                for (int i = 0; i < d; i++) (dst)[i] *= p->minv;                      \
         } else                                                                        \
             for (int i = 0; i < d; i++) (dst)[i] = (src)[i];                          \
     } while (0)
@@ -803,7 +807,8 @@ int orc_run_adapt(const orc_model *m, const orc_proposal *p, int64_t N, double *
  * `n` in the three formulas above is the pooled count N n.  For N = 1 this is the
  * reference's algorithm (np.float, removed from numpy, read as float; :81).
  *
- * st: [n, SX (d), SX2 (d*d), C (d*d), L (d*d)] updated in place; on the first call
+ * st: [n, SX (d), SX2 (d*d), C (d*d), L (d*d), minv] updated in place (minv: HMC variant only,
+ * 0 until the first update); on the first call
  * n = 0, sums 0, C = C0, L = cholesky(C0) (adaptive.py:59-67).  p supplies .scale.
  * Returns 0, -1 on a dimension mismatch, -2 if a covariance is not positive definite
  * (the reference raises LinAlgError there).
@@ -859,13 +864,17 @@ int orc_run_adaptcov(const orc_model *m, const orc_proposal *p, int64_t N, doubl
      * (randomwalk.py:62-75): the scale adaptation of adaptive.py:25-35 per chain, then the
      * covariance adaptation, after every step (:73-75) */
     const int d = m->d;
-    if (p->d != d || p->kind != ORC_RW) return -1;
+    if (p->d != d || (p->kind != ORC_RW && p->kind != ORC_HMC)) return -1;
     double *SX = st + 1, *SX2 = SX + d, *L = SX2 + 2 * (size_t)d * d;
     double *work = (double *)malloc(sizeof(double) * d * 6);
     double *xi = work, *thp = work + d, *w2 = work + 2 * d;
     orc_proposal q = *p;
-    q.L = L;
     q.nblk = 0;
+    if (p->kind == ORC_RW) q.L = L;
+    else { /* AdaptCovHMC.propose, hamiltonian.py:117-119: M, chM = C, L */
+        q.chM = L;
+        q.minv = st[0] > 0 && st[1 + d + 3 * (size_t)d * d] != 0.0 ? st[1 + d + 3 * (size_t)d * d] : 0.0;
+    }
     if (hist_theta) memcpy(hist_theta, theta, sizeof(double) * N * d);
     if (hist_logpost) memcpy(hist_logpost, logpost, sizeof(double) * N);
     int rc = 0;
@@ -874,9 +883,9 @@ int orc_run_adaptcov(const orc_model *m, const orc_proposal *p, int64_t N, doubl
             double *th = theta + c * d;
             u64 *sc = rng + 16 * c;
             orc_rng_normals(sc, d, xi);
-            orc_propose1(&q, m, th, xi, thp, w2, adapt ? adapt[3 * c + 2] : 1.0);
+            const double logq = orc_propose1(&q, m, th, xi, thp, w2, adapt ? adapt[3 * c + 2] : 1.0);
             const double lp_prop = orc_log_post1(m, thp, w2);
-            const double delta = lp_prop - logpost[c] - 0.0;
+            const double delta = lp_prop - logpost[c] - logq;
             const double mh = (delta < 0) ? delta : 0.0;
             const int acc = orc_log(orc_rng_uniform(sc)) < mh;
             if (acc) {
@@ -906,8 +915,13 @@ int orc_run_adaptcov(const orc_model *m, const orc_proposal *p, int64_t N, doubl
          * literally; the documented intent is available as the exact_squares variant. */
         const double n = st[0], r = sqrt(n);
         const int due = exact_squares ? (floor(r + 0.5) * floor(r + 0.5) == n) : (r * r == n);
-        if (due && n > 2)
+        if (due && n > 2) {
             rc = orc_adaptcov_update(st, C0, d, n * (double)N, t_adapt, marginalize, smooth);
+            if (p->kind == ORC_HMC) { /* from now on C = d^0.4 L L^T */
+                st[1 + d + 3 * (size_t)d * d] = pow((double)d, -0.4);
+                q.minv = st[1 + d + 3 * (size_t)d * d];
+            }
+        }
     }
     free(work);
     return rc;

@@ -141,6 +141,7 @@ struct rmh_proposal {
     double *d_Ltiles = nullptr;
     bool dirty = true;
     double *d_chM = nullptr, *d_V = nullptr, *d_VT = nullptr; // mass-matrix tile images (HMC)
+    double minv = 1.0;                                        // M^-1 = minv (chM chM^T)^-1
     int nblk = 0, blk_end[3] = {0, 0, 0};                     // block-mixture random walk
     double blk_p[3] = {0.0, 0.0, 0.0};
     // AdaptCovProposal (proposals/adaptive.py:38-103), pooled over the chains
@@ -166,6 +167,7 @@ struct rmh_state {
 };
 
 static int acov_ntri(const rmh_proposal *p);
+static int install_mass(rmh_proposal *p, const double *chM);
 static void acov_unpack(const rmh_proposal *p, const std::vector<double> &acc, std::vector<double> &Mm);
 static void acov_pack(const rmh_proposal *p, const std::vector<double> &Mm, std::vector<double> &acc);
 static bool cholesky_lower(const std::vector<double> &Cm, int d, std::vector<double> &L);
@@ -723,7 +725,8 @@ int rmh_proposal_set_adapt_cov(rmh_proposal_t p, const double *C0, double t_adap
                                int smooth_adapt, int exact_squares)
 {
     RMH_NEED_INIT();
-    if (!p || p->kind != kRW) return fail(RMH_ERR_PARAM, "set_adapt_cov: not a random-walk proposal");
+    if (!p || (p->kind != kRW && p->kind != kHMC))
+        return fail(RMH_ERR_PARAM, "set_adapt_cov: not a random-walk or HMC proposal");
     if (!C0) {
         p->acov = false;
         return RMH_OK;
@@ -743,6 +746,11 @@ int rmh_proposal_set_adapt_cov(rmh_proposal_t p, const double *C0, double t_adap
     p->acov_C = C;                 // adaptive.py:60-62: C = C0, L = cholesky(C0)
     p->L = L;
     p->dirty = true;
+    if (p->kind == kHMC) {         // AdaptCovHMC: M, chM = C, L (hamiltonian.py:117-119)
+        p->minv = 1.0;
+        int rcm = install_mass(p, L.data());
+        if (rcm) return rcm;
+    }
     const size_t n = (size_t)acov_ntri(p) * 256;
     (void)hipFree(p->d_acov_acc);
     (void)hipFree(p->d_acov_partial);
@@ -753,7 +761,7 @@ int rmh_proposal_set_adapt_cov(rmh_proposal_t p, const double *C0, double t_adap
     return RMH_OK;
 }
 
-// st: [n, SX (d), SX2 (d,d), C (d,d), L (d,d)] -- this rank's sums
+// st: [n, SX (d), SX2 (d,d), C (d,d), L (d,d), minv] -- this rank's sums; minv: HMC only
 int rmh_proposal_adapt_cov_get(rmh_proposal_t p, double *st)
 {
     if (!p || !p->acov || !st) return fail(RMH_ERR_PARAM, "adapt_cov_get: not an AdaptCov proposal");
@@ -770,6 +778,7 @@ int rmh_proposal_adapt_cov_get(rmh_proposal_t p, double *st)
         C[i] = p->acov_C[i];
         L[i] = p->L[i];
     }
+    L[(size_t)d * d] = p->kind == kHMC ? p->minv : 0.0;
     return RMH_OK;
 }
 
@@ -790,6 +799,10 @@ int rmh_proposal_adapt_cov_set(rmh_proposal_t p, const double *st, double count)
     p->acov_C.assign(C, C + (size_t)d * d);
     p->L.assign(L, L + (size_t)d * d);
     p->dirty = true;
+    if (p->kind == kHMC) {
+        p->minv = L[(size_t)d * d] != 0.0 ? L[(size_t)d * d] : 1.0;
+        return install_mass(p, p->L.data());
+    }
     return RMH_OK;
 }
 
@@ -819,10 +832,9 @@ int rmh_proposal_hmc_create(double eps, int nsteps, int d, rmh_proposal_t *out)
     return RMH_OK;
 }
 
-int rmh_proposal_hmc_set_mass(rmh_proposal_t p, const double *chM)
+// tile images of chM, V = chM^-1 and V^T for the mass-matrix kernels
+static int install_mass(rmh_proposal *p, const double *chM)
 {
-    RMH_NEED_INIT();
-    if (!p || p->kind != kHMC) return fail(RMH_ERR_PARAM, "mass matrix: not an HMC proposal");
     (void)hipFree(p->d_chM); (void)hipFree(p->d_V); (void)hipFree(p->d_VT);
     p->d_chM = p->d_V = p->d_VT = nullptr;
     if (!chM) return RMH_OK;
@@ -843,6 +855,15 @@ int rmh_proposal_hmc_set_mass(rmh_proposal_t p, const double *chM)
         (rc = upload(&p->d_VT, c.data(), c.size())))
         return rc;
     return RMH_OK;
+}
+
+int rmh_proposal_hmc_set_mass(rmh_proposal_t p, const double *chM)
+{
+    RMH_NEED_INIT();
+    if (!p || p->kind != kHMC) return fail(RMH_ERR_PARAM, "mass matrix: not an HMC proposal");
+    if (p->acov) return fail(RMH_ERR_PARAM, "mass matrix: owned by the covariance adaptation");
+    p->minv = 1.0;
+    return install_mass(p, chM);
 }
 
 int rmh_proposal_set_scale(rmh_proposal_t p, double scale)
@@ -927,7 +948,7 @@ int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
             }
         } else {
             if (p->d_chM) rc = fail(RMH_ERR_PARAM, "propose: stand-alone HMC proposals with a mass matrix are not built");
-            HmcArgs ha{p->eps, p->nsteps, nullptr, nullptr, nullptr};
+            HmcArgs ha{p->eps, p->nsteps, nullptr, nullptr, nullptr, 1.0};
             if (rc) {} else if (m->kind == kGauss) e = launch_gauss_propose_hmc(m->NT, m->ga, ha, c, outp, lq, g_stream);
             else if (m->kind == kLogReg) e = launch_logreg_propose_hmc(m->NT, m->la, ha, c, outp, lq, g_stream);
             else rc = fail(RMH_ERR_PARAM, "hmc: this model has no gradient");
@@ -1332,6 +1353,10 @@ static int acov_update(rmh_proposal *p)
     p->acov_C = Cn;
     p->L = L;
     p->dirty = true;
+    if (p->kind == kHMC) { // M = C = d^0.4 L L^T from now on, chM = L
+        p->minv = 1.0 / f4;
+        return install_mass(p, L.data());
+    }
     return sync_proposal(p);
 }
 
@@ -1378,7 +1403,13 @@ static int run_adaptcov(rmh_model *m, rmh_proposal *p, rmh_state *s, const Chain
         r.h_theta = s->sc_theta;
         r.h_logpost = s->sc_logpost;
         r.h_accept = s->sc_accept;
-        RMH_HIP(launch_rw_plain(m, p, c, r, c.adapt != nullptr));
+        if (p->kind == kHMC) {
+            HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT, p->minv};
+            RMH_HIP(m->kind == kGauss ? launch_gauss_hmc(m->NT, m->ga, ha, c, r, false, g_stream)
+                                      : launch_logreg_hmc(m->NT, m->la, ha, c, r, false, g_stream));
+        } else {
+            RMH_HIP(launch_rw_plain(m, p, c, r, c.adapt != nullptr));
+        }
         ++*launches;
         if (h) {
             for (int64_t i = (done == 0 ? 0 : 1); i <= seg; ++i) {
@@ -1464,9 +1495,11 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
         e = launch_big_gauss_rw(m->NT, m->ga, ra, c, r, g_stream);
     } else if (p->acov) {
-        if (K > 0 || p->kind != kRW || p->nblk > 0 || m->kind == kChangepoint)
+        if (K > 0 || p->kind == kPCN || p->nblk > 0 || m->kind == kChangepoint ||
+            (p->kind == kHMC && (adapt || m->kind == kMixture)))
             return fail(RMH_ERR_PARAM, "run: AdaptCov is built for the random walk (plain or with scale "
-                                       "adaptation) on the Gaussian, mixture and logistic models");
+                                       "adaptation) and for HMC on the Gaussian, mixture (random walk) "
+                                       "and logistic models");
         launches = 0;
         if ((rc = run_adaptcov(m, p, s, c, T, nburn, nthin, h, &launches))) return rc;
     } else if (K > 0) {
@@ -1497,7 +1530,7 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         else if (m->kind == kMixture) e = launch_mix_rw(m->NT, m->ma, ra, c, r, adapt, g_stream);
         else e = launch_logreg_rw(m->NT, m->la, ra, c, r, adapt, g_stream);
     } else {
-        HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT};
+        HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT, p->minv};
         if (m->kind == kMixture) return fail(RMH_ERR_PARAM, "hmc: MixtureDist has no gradient");
         if (m->kind == kGauss) e = launch_gauss_hmc(m->NT, m->ga, ha, c, r, adapt, g_stream);
         else e = launch_logreg_hmc(m->NT, m->la, ha, c, r, adapt, g_stream);

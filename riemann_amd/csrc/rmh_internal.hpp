@@ -99,6 +99,9 @@ struct HmcArgs {
     // mass matrix M (hamiltonian.py:71-74), or null: tile images in GLOBAL memory
     // (L2 resident; LDS is full) of chM = cholesky(M), V = chM^-1 and V^T
     const double *chM, *V, *VT;
+    // M^-1 = minv (chM chM^T)^-1.  1 for VanillaHMC(M); AdaptCovHMC sets M = C and chM = L
+    // with C = d^0.4 L L^T (hamiltonian.py:117-119 with adaptive.py:101-102): minv = d^-0.4
+    double minv;
 };
 
 // tile counts of the triangular images

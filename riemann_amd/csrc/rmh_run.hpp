@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
             tri_apply<NT, false>(pr.V + lane, psc, ch.ks);       // M^-1 p = V^T V p, :29
             tri_apply<NT, true>(pr.VT + lane, psc, ch.ks);
 #pragma unroll
-            for (int s = 0; s < S; ++s) q[s] = q[s] + eps * psc[s];
+            for (int s = 0; s < S; ++s) q[s] = q[s] + (eps * pr.minv) * psc[s];
         } else {
 #pragma unroll
             for (int s = 0; s < S; ++s) q[s] = q[s] + eps * p[s]; // :30
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
                     tri_apply<NT, false>(pr.V + lane, psc, ch.ks);   // :36
                     tri_apply<NT, true>(pr.VT + lane, psc, ch.ks);
 #pragma unroll
-                    for (int s = 0; s < S; ++s) q[s] = q[s] + eps * psc[s];
+                    for (int s = 0; s < S; ++s) q[s] = q[s] + (eps * pr.minv) * psc[s];
                 } else {
 #pragma unroll
                     for (int s = 0; s < S; ++s) q[s] = q[s] + eps * p[s]; // :37

@@ -72,7 +72,7 @@ class AdaptCovProposal(DeviceProposal):
 
     def _adapt_cov_state(self):
         d = self.C0.shape[0]
-        st = np.empty(1 + d + 3 * d * d)
+        st = np.empty(2 + d + 3 * d * d)
         _lib.call("rmh_proposal_adapt_cov_get", self._h, st)
         return st
 
@@ -84,7 +84,7 @@ class AdaptCovProposal(DeviceProposal):
         self._SX = st[1:1 + d].copy()
         self._SX2 = st[1 + d:1 + d + d * d].reshape(d, d).copy()
         self.C = st[1 + d + d * d:1 + d + 2 * d * d].reshape(d, d).copy()
-        self.L = st[1 + d + 2 * d * d:].reshape(d, d).copy()
+        self.L = st[1 + d + 2 * d * d:1 + d + 3 * d * d].reshape(d, d).copy()
 
     def propose(self, theta):
         raise NotImplementedError("stand-alone propose() of an adaptive proposal is not built")

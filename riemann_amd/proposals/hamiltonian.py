@@ -12,7 +12,7 @@ import numpy as np
 
 from .. import _lib
 from ..models.model import DeviceModel
-from .adaptive import AdaptScaleProposal
+from .adaptive import AdaptCovProposal, AdaptScaleProposal
 from .proposal import DeviceProposal
 
 
@@ -68,3 +68,36 @@ class AdaptScaleHMC(AdaptScaleProposal, VanillaHMC):
 
     def _sync(self):
         _lib.call("rmh_proposal_set_eps", self._h, float(self.eps0))
+
+
+class AdaptCovHMC(AdaptCovProposal, VanillaHMC):
+    """HMC whose mass matrix follows the covariance of the chain history
+    (hamiltonian.py:107-120): before every proposal ``M, chM = C, L`` of the covariance
+    adaptation (AdaptCovProposal, pooled over the chains here).  As in the reference, after
+    the first update ``chM`` is not the Cholesky factor of ``M`` but ``M = d^0.4 chM chM^T``
+    (adaptive.py:101-102): momenta are drawn and weighed with ``chM``, positions drift with
+    ``M^-1``."""
+
+    def __init__(self, eps, Nsteps, gradlogpost, M0, t_adapt=1, marginalize=False, smooth_adapt=False,
+                 exact_squares=False):
+        VanillaHMC.__init__(self, eps, Nsteps, gradlogpost, M=None)
+        self._init_adapt_cov(M0, t_adapt=t_adapt, marginalize=marginalize, smooth_adapt=smooth_adapt,
+                             exact_squares=exact_squares)
+        self.M, self.chM = self.C, self.L
+
+    def _pull_adapt(self, state, single):
+        AdaptCovProposal._pull_adapt(self, state, single)
+        self.M, self.chM = self.C, self.L
+
+
+class AdaptScaleCovHMC(AdaptScaleHMC):
+    """hamiltonian.py:123-134.  The reference class defines no ``adapt`` of its own, so
+    Python's method resolution order finds ``AdaptScaleProposal.adapt`` and the covariance
+    part never runs: the sampler is AdaptScaleHMC with the constant mass matrix ``M0``
+    (``C``, ``L`` stay at their initial values).  Reproduced as that."""
+
+    def __init__(self, eps, Nsteps, gradlogpost, M0, t_adapt=1, marginalize=False, smooth_adapt=False):
+        AdaptScaleHMC.__init__(self, eps, Nsteps, gradlogpost, M=M0)
+        self.C0 = self.C = self.M
+        self.L = self.chM
+        self.t_adapt, self.marginalize, self.smooth_adapt = t_adapt, marginalize, smooth_adapt

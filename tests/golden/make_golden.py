@@ -594,6 +594,24 @@ def g14_adapt_cov():
                                              "Naccepts": np.int64(p.Naccepts)})
         r.pop("xi")
         save("g14_adaptscalecov_10d", Ct=Ct, C0=0.1 * np.eye(d), t_adapt=np.float64(30), **r)
+        # AdaptCovHMC / AdaptScaleCovHMC (hamiltonian.py:107-134): the adapted covariance is the mass matrix
+        from riemann.proposals.hamiltonian import AdaptCovHMC, AdaptScaleCovHMC
+        M0 = 0.5 * np.eye(d)
+        cap = lambda p: {"C_final": np.array(p.C), "L_final": np.array(p.L)}        # noqa: E731
+        r = run_reference(m10, lambda: AdaptCovHMC(0.25, 4, m10.grad_log_likelihood, M0, t_adapt=40,
+                                                   smooth_adapt=True),
+                          g.standard_normal((2, d)), seed=147, T=60, capture=cap)
+        r.pop("xi")
+        save("g14_adaptcovhmc_10d", Ct=Ct, M0=M0, eps=np.float64(0.25), nsteps=np.int64(4),
+             t_adapt=np.float64(40), **r)
+        cap2 = lambda p: {"C_final": np.array(p.C), "L_final": np.array(p.L),       # noqa: E731
+                          "scale_final": np.float64(p.scale)}
+        r = run_reference(m10, lambda: AdaptScaleCovHMC(0.25, 3, m10.grad_log_likelihood, M0, t_adapt=40,
+                                                        smooth_adapt=True),
+                          g.standard_normal((2, d)), seed=148, T=60, capture=cap2)
+        r.pop("xi")
+        save("g14_adaptscalecovhmc_10d", Ct=Ct, M0=M0, eps=np.float64(0.25), nsteps=np.int64(3),
+             t_adapt=np.float64(40), **r)
     finally:
         if not had:
             del np.float

@@ -1087,3 +1087,46 @@ def test_g14_adaptive_scale_and_covariance_fixture_and_many_chains(ra, orc):
     np.testing.assert_allclose(s._chain_thetas, ht, rtol=1e-8, atol=1e-11)
     np.testing.assert_allclose(p.scale, ad[:, 2], rtol=1e-12)
     np.testing.assert_allclose(p.C, orc.adaptcov_CL(stc, 10)[0], rtol=1e-9, atol=1e-15)
+
+
+def test_g14_adaptive_covariance_hmc_fixtures_and_many_chains(ra, orc):
+    """AdaptCovHMC (adapted covariance = mass matrix, with the reference's M / chM mismatch)
+    and AdaptScaleCovHMC (whose covariance part never runs in the reference)."""
+    from riemann_amd.models import LogisticRegression, MultiGaussianDist
+    from riemann_amd.proposals import AdaptCovHMC, AdaptScaleCovHMC
+    from riemann_amd.workloads import logreg_data
+    z = load("g14_adaptcovhmc_10d")
+    m = MultiGaussianDist(np.zeros(10), z["Ct"])
+    for c in range(2):
+        p = AdaptCovHMC(float(z["eps"]), int(z["nsteps"]), m, z["M0"], t_adapt=float(z["t_adapt"]), smooth_adapt=True)
+        s = ra.Sampler(m, p, z["theta0"][c], seed=int(z["seed"]), chain0=c)
+        s.run(60)
+        np.testing.assert_array_equal(s._chain_accept, z["accept"][:, c])
+        np.testing.assert_allclose(s._chain_thetas, z["thetas"][:, c], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(s._chain_logpost, z["logpost"][:, c], rtol=1e-8)
+        np.testing.assert_allclose(p.chM, z["L_final"][c], rtol=1e-8, atol=1e-14)
+        np.testing.assert_allclose(p.M, z["C_final"][c], rtol=1e-8, atol=1e-14)
+    z = load("g14_adaptscalecovhmc_10d")
+    for c in range(2):
+        p = AdaptScaleCovHMC(float(z["eps"]), int(z["nsteps"]), m, z["M0"], t_adapt=40, smooth_adapt=True)
+        s = ra.Sampler(m, p, z["theta0"][c], seed=int(z["seed"]), chain0=c)
+        s.run(60)
+        np.testing.assert_array_equal(s._chain_accept, z["accept"][:, c])
+        np.testing.assert_allclose(s._chain_thetas, z["thetas"][:, c], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(p.scale, z["scale_final"][c], rtol=1e-12)
+        np.testing.assert_array_equal(p.C, z["C_final"][c])
+    # pooled over chains, logistic target (two waves per SIMD variant is not used with a mass matrix)
+    X, y = logreg_data(400, 24, seed=6)
+    ml, ol = LogisticRegression(X, y, 100.0), orc.LogReg(X, y, 100.0)
+    N, T, M0 = 300, 30, 40.0 * np.eye(24)
+    th0 = 0.05 * np.random.default_rng(5).standard_normal((N, 24))
+    p = AdaptCovHMC(0.9, 3, ml, M0, t_adapt=500, smooth_adapt=True)
+    s = ra.Sampler(ml, p, th0, seed=14)
+    s.run(T)
+    th, st, stc = th0.copy(), orc.rng_seed(14, N), orc.new_adaptcov_state(M0)
+    ht, hl, acc = orc.run_adaptcov(ol, orc.HMC(0.9, 3, 24, M=M0), th, ol.log_posterior(th), st, T, stc, M0,
+                                   t_adapt=500, smooth_adapt=True)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(p.C, orc.adaptcov_CL(stc, 24)[0], rtol=1e-8, atol=1e-14)
+    assert 0.05 < acc.mean() < 0.99 and acc[:4].mean() > 0.5

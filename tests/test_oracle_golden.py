@@ -427,3 +427,33 @@ def test_g14_adaptive_scale_and_covariance_10d():
     np.testing.assert_allclose(ad[0, 2], z["scale_final"][0], rtol=1e-12)
     assert ad[0, 1] == z["Naccepts"][0]
     np.testing.assert_allclose(orc.adaptcov_CL(stc, 10)[1], z["L_final"][0], rtol=1e-8, atol=1e-14)
+
+
+@pytest.mark.parametrize("name,adaptive", [("g14_adaptcovhmc_10d", False), ("g14_adaptscalecovhmc_10d", True)])
+def test_g14_adaptive_covariance_hmc(name, adaptive):
+    """AdaptCovHMC (hamiltonian.py:107-120): the adapted covariance is the mass matrix.
+    AdaptScaleCovHMC (:123-134) defines no adapt() of its own, so the method resolution order
+    finds AdaptScaleProposal.adapt only: the scale adapts, the covariance never does, and the
+    class is AdaptScaleHMC with the constant mass matrix M0 -- restated as that.
+    Each chain of a fixture is an independent single-chain reference run."""
+    z = load(name)
+    model = orc.Gaussian(np.zeros(10), z["Ct"])
+    T = z["accept"].shape[0]
+    for c in range(z["theta0"].shape[0]):
+        th = np.ascontiguousarray(z["theta0"][c:c + 1]).copy()
+        st = orc.rng_seed(int(z["seed"]), c + 1)[c:c + 1].copy()
+        prop = orc.HMC(float(z["eps"]), int(z["nsteps"]), 10, M=z["M0"])
+        lp = model.log_posterior(th)
+        if adaptive:
+            ad = orc.new_adapt_state(1)
+            ht, hl, acc = orc.run(model, orc.set_adapt(prop, 0.75), th, lp, st, T, adapt=ad)
+            np.testing.assert_allclose(ad[0, 2], z["scale_final"][c], rtol=1e-12)
+            np.testing.assert_array_equal(z["C_final"][c], z["M0"])        # never adapted
+        else:
+            stc = orc.new_adaptcov_state(z["M0"])
+            ht, hl, acc = orc.run_adaptcov(model, prop, th, lp, st, T, stc, z["M0"],
+                                           t_adapt=float(z["t_adapt"]), smooth_adapt=True)
+            np.testing.assert_allclose(orc.adaptcov_CL(stc, 10)[1], z["L_final"][c], rtol=1e-8, atol=1e-14)
+        np.testing.assert_array_equal(acc[:, 0], z["accept"][:, c])
+        np.testing.assert_allclose(ht[:, 0], z["thetas"][:, c], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(hl[:, 0], z["logpost"][:, c], rtol=1e-8)

@@ -96,14 +96,14 @@ int rmh_proposal_rw_create(const double *L, int d, double scale, rmh_proposal_t 
  * trans-dimensional branch (:56-71), which does not exist at fixed k: theta' = theta.
  * nblk = 0 returns to the full-vector random walk.  (Changepoint model, fused run only.) */
 int rmh_proposal_rw_set_blocks(rmh_proposal_t p, int nblk, const int *sizes, const double *pcum);
-/* pCN(C, rho), proposals/randomwalk.py:78-101.  L = cholesky(C).  (Fused run only;
- * Gaussian, mixture and logistic models.) */
+/* pCN(C, rho), proposals/randomwalk.py:78-101.  L = cholesky(C).  (Gaussian, mixture and
+ * logistic models.) */
 int rmh_proposal_pcn_create(const double *L, int d, double rho, rmh_proposal_t *out);
 /* VanillaHMC(eps, Nsteps, gradlogpost, M=None), proposals/hamiltonian.py:60-91;
  * the gradient is the device Model's.  Nsteps = 1 is MALA. */
 int rmh_proposal_hmc_create(double eps, int nsteps, int d, rmh_proposal_t *out);
 /* VanillaHMC(..., M): mass matrix, hamiltonian.py:71-74.  chM = cholesky(M), lower,
- * (d,d) row-major; NULL removes it.  (Fused run only; rmh_propose takes M = None.) */
+ * (d,d) row-major; NULL removes it. */
 int rmh_proposal_hmc_set_mass(rmh_proposal_t p, const double *chM);
 int rmh_proposal_set_scale(rmh_proposal_t p, double scale); /* .scale, randomwalk.py:18 */
 int rmh_proposal_set_eps(rmh_proposal_t p, double eps);     /* .eps, hamiltonian.py:69 */

@@ -935,7 +935,13 @@ int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
     if (e == hipSuccess) e = hipMemsetAsync(outp, 0, (size_t)s.dp * s.ld * sizeof(double), g_stream);
     if (e == hipSuccess) {
         if (p->kind == kPCN) {
-            rc = fail(RMH_ERR_PARAM, "propose: stand-alone pCN proposals are not built");
+            rc = sync_proposal(p);
+            if (!rc) {
+                RwArgs ra{p->d_Ltiles, p->d_V, p->rho};
+                e = launch_propose_rw(p->NT, ra, c, outp, lq, g_stream); // randomwalk.py:89-101
+            }
+        } else if (p->kind == kRW && p->acov) {
+            rc = fail(RMH_ERR_PARAM, "propose: stand-alone proposals of an adaptive proposal are not built");
         } else if (p->kind == kRW && p->nblk > 0) {
             rc = fail(RMH_ERR_PARAM, "propose: stand-alone block-mixture proposals are not built");
         } else if (p->kind == kRW && p->NT > 7) {
@@ -944,11 +950,11 @@ int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
             rc = sync_proposal(p);
             if (!rc) {
                 RwArgs ra{p->d_Ltiles, nullptr, 0.0};
-                e = launch_propose_rw(p->NT, ra, c, outp, g_stream); // logqratio = 0.0, randomwalk.py:26
+                e = launch_propose_rw(p->NT, ra, c, outp, lq, g_stream); // logqratio = 0.0, randomwalk.py:26
             }
         } else {
-            if (p->d_chM) rc = fail(RMH_ERR_PARAM, "propose: stand-alone HMC proposals with a mass matrix are not built");
-            HmcArgs ha{p->eps, p->nsteps, nullptr, nullptr, nullptr, 1.0};
+            if (p->acov) rc = fail(RMH_ERR_PARAM, "propose: stand-alone proposals of an adaptive proposal are not built");
+            HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT, p->minv};
             if (rc) {} else if (m->kind == kGauss) e = launch_gauss_propose_hmc(m->NT, m->ga, ha, c, outp, lq, g_stream);
             else if (m->kind == kLogReg) e = launch_logreg_propose_hmc(m->NT, m->la, ha, c, outp, lq, g_stream);
             else rc = fail(RMH_ERR_PARAM, "hmc: this model has no gradient");

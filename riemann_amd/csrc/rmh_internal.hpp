@@ -137,7 +137,7 @@ hipError_t launch_gauss_pcn(int NT, const GaussArgs &m, const RwArgs &p, const C
 hipError_t launch_gauss_hmc(int NT, const GaussArgs &m, const HmcArgs &p, const ChainArgs &c,
                             const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_propose_rw(int NT, const RwArgs &p, const ChainArgs &c, double *theta_p,
-                             hipStream_t st);
+                             double *logq, hipStream_t st);
 hipError_t launch_gauss_propose_hmc(int NT, const GaussArgs &m, const HmcArgs &p,
                                     const ChainArgs &c, double *theta_p, double *logq,
                                     hipStream_t st);

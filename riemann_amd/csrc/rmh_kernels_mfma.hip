@@ -133,12 +133,14 @@ hipError_t launch_gauss_hmc(int NT, const GaussArgs &m, const HmcArgs &p, const 
     })
 }
 
+// p.Vtiles != null: the pCN proposal (logq written), else the random walk
 hipError_t launch_propose_rw(int NT, const RwArgs &p, const ChainArgs &c, double *theta_p,
-                             hipStream_t st)
+                             double *logq, hipStream_t st)
 {
     RMH_NT_DISPATCH(NT, {
         const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + kIcdfDoubles);
-        return launch(k_propose_rw<kNT, 4>, c.nblocks, 4, lds, st, p, c, theta_p);
+        if (p.Vtiles) return launch(k_propose_rw<kNT, 4, true>, c.nblocks, 4, lds, st, p, c, theta_p, logq);
+        return launch(k_propose_rw<kNT, 4, false>, c.nblocks, 4, lds, st, p, c, theta_p, logq);
     })
 }
 
@@ -149,7 +151,8 @@ hipError_t launch_gauss_propose_hmc(int NT, const GaussArgs &m, const HmcArgs &p
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
         const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
-        return launch(k_propose_hmc<M, 4>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
+        if (p.chM) return launch(k_propose_hmc<M, 4, true>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
+        return launch(k_propose_hmc<M, 4, false>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
     })
 }
 
@@ -222,7 +225,8 @@ hipError_t launch_logreg_propose_hmc(int NT, const LogRegArgs &m, const HmcArgs 
     RMH_NT_DISPATCH(NT, {
         using M = LogRegModel<kNT>;
         const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
-        return launch(k_propose_hmc<M, 4>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
+        if (p.chM) return launch(k_propose_hmc<M, 4, true>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
+        return launch(k_propose_hmc<M, 4, false>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
     })
 }
 

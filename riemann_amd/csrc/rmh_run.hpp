@@ -403,9 +403,10 @@ __global__ void __launch_bounds__(64 * NW) k_eval(typename M::Args m, ChainArgs 
     }
 }
 
-// MetropolisRandomWalk.propose for the states in ch.theta (advances ch.rng)
-template <int NT, int NW>
-__global__ void __launch_bounds__(64 * NW) k_propose_rw(RwArgs pr, ChainArgs ch, double *theta_p)
+// MetropolisRandomWalk.propose (randomwalk.py:21-26) or pCN.propose (:89-101) for the states
+// in ch.theta (advances ch.rng); logq_out is written for pCN only (0 for the random walk)
+template <int NT, int NW, bool PCN>
+__global__ void __launch_bounds__(64 * NW) k_propose_rw(RwArgs pr, ChainArgs ch, double *theta_p, double *logq_out)
 {
     constexpr int S = 4 * NT;
     using T = Tile<NT>;
@@ -424,15 +425,41 @@ __global__ void __launch_bounds__(64 * NW) k_propose_rw(RwArgs pr, ChainArgs ch,
     Xo rng = xo_load(ch.rng, ch.nslots, slot);
     T::normals(rng, ch.M, ch.d, g, tab, xi);
     double4_t acc[NT];
-    T::pack(th, acc);
-    T::mul_lower(lds + lane, xi, acc, ch.ks);
-    T::unpack(acc, th);
-    T::store_state(theta_p, ch.ld, c, g, th);
+    if (PCN) {
+        double thp[S], ufw[S], urv[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) thp[s] = pr.rho * th[s];
+        T::pack(thp, acc);
+        T::mul_lower(lds + lane, xi, acc, ch.ks);   // image holds rho_c * L
+        T::unpack(acc, thp);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            ufw[s] = thp[s] - pr.rho * th[s];
+            urv[s] = th[s] - pr.rho * thp[s];
+        }
+        tri_apply<NT, false>(pr.Vtiles + lane, ufw, ch.ks);
+        tri_apply<NT, false>(pr.Vtiles + lane, urv, ch.ks);
+        double sf = 0.0, sr = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            sf += ufw[s] * ufw[s];
+            sr += urv[s] * urv[s];
+        }
+        const double logq = -0.5 * (sum4(sf) - sum4(sr));
+        T::store_state(theta_p, ch.ld, c, g, thp);
+        if (g == 0) logq_out[c] = logq;
+    } else {
+        T::pack(th, acc);
+        T::mul_lower(lds + lane, xi, acc, ch.ks);
+        T::unpack(acc, th);
+        T::store_state(theta_p, ch.ld, c, g, th);
+    }
     xo_store(ch.rng, ch.nslots, slot, rng);
 }
 
-// VanillaHMC.propose for the states in ch.theta (advances ch.rng)
-template <class M, int NW>
+// VanillaHMC.propose for the states in ch.theta (advances ch.rng); MASS: with a mass matrix
+// (hamiltonian.py:80-81, 29, 36, 85-87), tile images read from global memory
+template <class M, int NW, bool MASS>
 __global__ void __launch_bounds__(64 * NW) k_propose_hmc(typename M::Args m, HmcArgs pr, ChainArgs ch, double *theta_p,
                               double *logq_out)
 {
@@ -456,29 +483,40 @@ __global__ void __launch_bounds__(64 * NW) k_propose_hmc(typename M::Args m, Hmc
     double k0 = 0.0;
 #pragma unroll
     for (int s = 0; s < S; ++s) k0 += p[s] * p[s];
+    if (MASS) tri_apply<NT, false>(pr.chM + lane, p, ch.ks);
     const double eps = pr.eps, heps = 0.5 * pr.eps;
+    auto drift = [&]() {
+        if (MASS) {
+            double psc[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) psc[s] = p[s];
+            tri_apply<NT, false>(pr.V + lane, psc, ch.ks);
+            tri_apply<NT, true>(pr.VT + lane, psc, ch.ks);
+#pragma unroll
+            for (int s = 0; s < S; ++s) q[s] = q[s] + (eps * pr.minv) * psc[s];
+        } else {
+#pragma unroll
+            for (int s = 0; s < S; ++s) q[s] = q[s] + eps * p[s];
+        }
+    };
     M::template eval<true>(lds, m, true, lane, q, lpp, gr, parts);
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        p[s] = p[s] + heps * gr[s];
-        q[s] = q[s] + eps * p[s];
-    }
+    for (int s = 0; s < S; ++s) p[s] = p[s] + heps * gr[s];
+    drift();
     for (int step = 1; step < pr.nsteps; ++step) {
         asm volatile("" ::: "memory");
         M::template eval<true>(lds, m, true, lane, q, lpp, gr, parts);
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            p[s] = p[s] + eps * gr[s];
-            q[s] = q[s] + eps * p[s];
-        }
+        for (int s = 0; s < S; ++s) p[s] = p[s] + eps * gr[s];
+        drift();
     }
     M::template eval<true>(lds, m, true, lane, q, lpp, gr, parts);
+#pragma unroll
+    for (int s = 0; s < S; ++s) p[s] = p[s] + heps * gr[s];
+    if (MASS) tri_apply<NT, false>(pr.V + lane, p, ch.ks);
     double k1 = 0.0;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        p[s] = p[s] + heps * gr[s];
-        k1 += p[s] * p[s];
-    }
+    for (int s = 0; s < S; ++s) k1 += p[s] * p[s];
     const double logq = 0.5 * (sum4(k1) - sum4(k0));
     if (active) {
         T::store_state(theta_p, ch.ld, c, g, q);

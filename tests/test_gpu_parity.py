@@ -170,6 +170,23 @@ def test_propose_vs_oracle(ra, orc):
         np.testing.assert_allclose(logq, elogq, rtol=1e-7, atol=1e-9)
     t1, q1 = p.propose(th[0])                           # single state in, single state out
     assert t1.shape == (d,) and q1 == 0.0
+    # pCN (asymmetric logqratio) and HMC with a mass matrix, stand-alone
+    from riemann_amd.proposals import pCN
+    pc = pCN(0.05 * Ct, 0.9)
+    pc.seed(11)
+    thp, logq = pc.propose(th)
+    ethp, elogq = orc.PCN(0.05 * Ct, 0.9).propose(orc.Gaussian(np.zeros(d), Ct), th, orc.rng_seed(11, N))
+    np.testing.assert_allclose(thp, ethp, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(logq, elogq, rtol=1e-7, atol=1e-8)
+    assert np.abs(logq).max() > 1.0
+    A = g.standard_normal((d, d))
+    Mm = A @ A.T / d + 0.5 * np.eye(d)
+    h = VanillaHMC(0.15, 3, m, M=Mm)
+    h.seed(12)
+    thp, logq = h.propose(th)
+    ethp, elogq = orc.HMC(0.15, 3, d, M=Mm).propose(orc.Gaussian(np.zeros(d), Ct), th, orc.rng_seed(12, N))
+    np.testing.assert_allclose(thp, ethp, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(logq, elogq, rtol=1e-7, atol=1e-8)
 
 
 # ------------------------------------------- fixtures recorded from the reference

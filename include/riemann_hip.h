@@ -110,7 +110,8 @@ int rmh_proposal_set_eps(rmh_proposal_t p, double eps);     /* .eps, hamiltonian
 /* AdaptScaleProposal mix-in, proposals/adaptive.py:11-35: AdaptScaleRandomWalk
  * (randomwalk.py:29-38, target 0.25) and AdaptScaleHMC (hamiltonian.py:94-104,
  * target 0.75, eps = scale * eps0).  target > 0 switches the proposal to its
- * adaptive variant; the per-chain state [Nsamples, Naccepts, scale] lives with the
+ * adaptive variant (on a pCN proposal: AdaptScalepCN, randomwalk.py:104-119, target 0.25,
+ * Gaussian model); the per-chain state [Nsamples, Naccepts, scale] lives with the
  * chains (rmh_state_get_adapt / rmh_state_set_adapt, (N,3) float64). */
 int rmh_proposal_set_adapt(rmh_proposal_t p, double target_accept_rate);
 /* AdaptCovProposal mix-in (Haario et al. 2001), proposals/adaptive.py:38-103, as
@@ -155,6 +156,10 @@ int rmh_state_get_rng(rmh_state_t s, uint64_t *rng);   /* (N,16) */
 int rmh_state_set_rng(rmh_state_t s, const uint64_t *rng);
 int rmh_state_get_adapt(rmh_state_t s, double *adapt);       /* (N,3) */
 int rmh_state_set_adapt(rmh_state_t s, const double *adapt);
+/* the auxiliary per-chain value of an adaptive proposal, (N) float64: AdaptScalepCN's
+ * recursive rho (randomwalk.py:118); NaN = not started */
+int rmh_state_get_adapt_aux(rmh_state_t s, double *aux);
+int rmh_state_set_adapt_aux(rmh_state_t s, const double *aux);
 int rmh_state_device_ptrs(rmh_state_t s, void **theta_dn, void **logpost,
                           int64_t *ld);                 /* theta is (d, ld) on device */
 int rmh_state_free(rmh_state_t s);

@@ -69,7 +69,7 @@ def lib():
     L.orc_proposal_set_adapt.argtypes = [vp, dbl]
     L.orc_proposal_set_mass.argtypes = [vp, vp]
     L.orc_run_adapt.restype = i32
-    L.orc_run_adapt.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, vp, vp, vp, i32, vp]
+    L.orc_run_adapt.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, vp, vp, vp, i32, vp, vp]
     L.orc_run.restype = i32
     L.orc_run.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, vp, vp, vp, i32]
     L.orc_rng_normals.argtypes = [_u64p, i32, _f64p]
@@ -292,7 +292,7 @@ def new_adapt_state(N):
     return a
 
 
-def run(model, proposal, theta, logpost, rng_state, T, history=True, nthreads=0, adapt=None):
+def run(model, proposal, theta, logpost, rng_state, T, history=True, nthreads=0, adapt=None, aux=None):
     """Sampler.run over N chains (/root/reference/riemann/samplers/sampler.py:44-90).
 
     ``theta`` (N,d), ``logpost`` (N,), ``rng_state`` (N,16) are advanced in
@@ -308,7 +308,8 @@ def run(model, proposal, theta, logpost, rng_state, T, history=True, nthreads=0,
                              ht.ctypes.data if history else None,
                              hl.ctypes.data if history else None,
                              acc.ctypes.data, nthreads,
-                             adapt.ctypes.data if adapt is not None else None)
+                             adapt.ctypes.data if adapt is not None else None,
+                             aux.ctypes.data if aux is not None else None)
     if rc != 0:
         raise ValueError("oracle: model and proposal dimensions differ")
     return ht, hl, acc

@@ -712,19 +712,22 @@ void orc_propose(const orc_proposal *p, const orc_model *m, const double *theta,
  * (adaptive.py:18-23), updated in place by adapt() after every step (sampler.py:88). */
 int orc_run_adapt(const orc_model *m, const orc_proposal *p, int64_t N, double *theta,
                   double *logpost, u64 *rng, int T, double *hist_theta, double *hist_logpost,
-                  uint8_t *accept, int nthreads, double *adapt);
+                  uint8_t *accept, int nthreads, double *adapt, double *aux);
 
 int orc_run(const orc_model *m, const orc_proposal *p, int64_t N, double *theta,
             double *logpost, u64 *rng, int T, double *hist_theta, double *hist_logpost,
             uint8_t *accept, int nthreads)
 {
     return orc_run_adapt(m, p, N, theta, logpost, rng, T, hist_theta, hist_logpost, accept,
-                         nthreads, NULL);
+                         nthreads, NULL, NULL);
 }
 
+/* aux (N) or NULL: AdaptScalepCN's per-chain rho (randomwalk.py:104-119): before every
+ * proposal rho <- tanh(rho / scale) (:118), a recursion on the chain's own rho; rho_c keeps
+ * its initial value.  NaN entries start from the proposal's rho. */
 int orc_run_adapt(const orc_model *m, const orc_proposal *p, int64_t N, double *theta,
                   double *logpost, u64 *rng, int T, double *hist_theta, double *hist_logpost,
-                  uint8_t *accept, int nthreads, double *adapt)
+                  uint8_t *accept, int nthreads, double *adapt, double *aux)
 {
     const int d = m->d;
     if (p->d != d) return -1;
@@ -754,7 +757,12 @@ int orc_run_adapt(const orc_model *m, const orc_proposal *p, int64_t N, double *
                     for (int j = 0; j < d; j++)
                         if (j < lo || j >= hi) xi[j] = 0.0;
                 }
-                const double logq = orc_propose1(p, m, th, xi, thp, w2, adapt ? adapt[3 * c + 2] : 1.0);
+                orc_proposal q = *p;
+                if (aux && adapt && p->kind == ORC_PCN && p->adapt_target > 0) {
+                    const double r0 = (aux[c] != aux[c]) ? p->rho : aux[c];
+                    aux[c] = q.rho = tanh(r0 / adapt[3 * c + 2]);
+                }
+                const double logq = orc_propose1(&q, m, th, xi, thp, w2, adapt ? adapt[3 * c + 2] : 1.0);
                 const double lp_prop = orc_log_post1(m, thp, w2);
                 const double delta = lp_prop - logpost[c] - logq;
                 const double mh = (delta < 0) ? delta : 0.0;

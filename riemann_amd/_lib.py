@@ -60,6 +60,8 @@ SIGNATURES = {
     "rmh_state_set_rng": [_vp, _u64],
     "rmh_state_get_adapt": [_vp, _f64],
     "rmh_state_set_adapt": [_vp, _f64],
+    "rmh_state_get_adapt_aux": [_vp, _f64],
+    "rmh_state_set_adapt_aux": [_vp, _f64],
     "rmh_state_device_ptrs": [_vp, _pvp, _pvp, C.POINTER(_i64)],
     "rmh_state_free": [_vp],
     "rmh_history_create": [_vp, _i64, _i64, _pvp],

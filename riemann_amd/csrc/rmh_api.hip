@@ -1072,8 +1072,13 @@ int rmh_state_set_rng(rmh_state_t s, const uint64_t *rng)
 static int ensure_adapt(rmh_state *s)
 {
     if (s->adapt) return RMH_OK;
-    std::vector<double> init((size_t)3 * s->ld, 0.0);
-    for (int64_t c = 0; c < s->ld; ++c) init[2 * s->ld + c] = 1.0; // adaptive.py:23
+    // rows: Nsamples, Naccepts, scale (adaptive.py:18-23) and one auxiliary per-chain value
+    // (AdaptScalepCN's recursive rho; NaN = not started)
+    std::vector<double> init((size_t)4 * s->ld, 0.0);
+    for (int64_t c = 0; c < s->ld; ++c) {
+        init[2 * s->ld + c] = 1.0; // adaptive.py:23
+        init[3 * s->ld + c] = std::nan("");
+    }
     return upload(&s->adapt, init.data(), init.size());
 }
 
@@ -1102,6 +1107,28 @@ int rmh_state_set_adapt(rmh_state_t s, const double *adapt)
     for (int64_t c = 0; c < s->N; ++c)
         for (int k = 0; k < 3; ++k) h[(size_t)k * s->ld + c] = adapt[c * 3 + k];
     RMH_HIP(hipMemcpyAsync(s->adapt, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    RMH_HIP(hipStreamSynchronize(g_stream));
+    return RMH_OK;
+}
+
+int rmh_state_get_adapt_aux(rmh_state_t s, double *aux)
+{
+    RMH_NEED_INIT();
+    if (!s || !aux) return fail(RMH_ERR_PARAM, "bad argument");
+    int rc = ensure_adapt(s);
+    if (rc) return rc;
+    RMH_HIP(hipMemcpyAsync(aux, s->adapt + 3 * s->ld, (size_t)s->N * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    RMH_HIP(hipStreamSynchronize(g_stream));
+    return RMH_OK;
+}
+
+int rmh_state_set_adapt_aux(rmh_state_t s, const double *aux)
+{
+    RMH_NEED_INIT();
+    if (!s || !aux) return fail(RMH_ERR_PARAM, "bad argument");
+    int rc = ensure_adapt(s);
+    if (rc) return rc;
+    RMH_HIP(hipMemcpyAsync(s->adapt + 3 * s->ld, aux, (size_t)s->N * sizeof(double), hipMemcpyHostToDevice, g_stream));
     RMH_HIP(hipStreamSynchronize(g_stream));
     return RMH_OK;
 }
@@ -1516,8 +1543,9 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
     } else if (p->kind == kPCN) {
         RwArgs ra{p->d_Ltiles, p->d_V, p->rho};
         if (m->kind == kChangepoint) return fail(RMH_ERR_PARAM, "run: pCN is not built for the changepoint kernel");
-        if (adapt) return fail(RMH_ERR_PARAM, "run: AdaptScalepCN is not built");
-        e = m->kind == kGauss    ? launch_gauss_pcn(m->NT, m->ga, ra, c, r, g_stream)
+        if (adapt && m->kind != kGauss)
+            return fail(RMH_ERR_PARAM, "run: AdaptScalepCN is built for the Gaussian model only");
+        e = m->kind == kGauss    ? launch_gauss_pcn(m->NT, m->ga, ra, c, r, adapt, g_stream)
             : m->kind == kLogReg ? launch_logreg_pcn(m->NT, m->la, ra, c, r, g_stream)
                                  : launch_mix_pcn(m->NT, m->ma, ra, c, r, g_stream);
     } else if (p->kind == kRW) {

@@ -109,11 +109,12 @@ hipError_t launch_mix_pcn(int NT, const MixArgs &m, const RwArgs &p, const Chain
 }
 
 hipError_t launch_gauss_pcn(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
-                            const RunArgs &r, hipStream_t st)
+                            const RunArgs &r, bool adapt, hipStream_t st)
 {
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
         const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false) + kIcdfDoubles);
+        if (adapt) return launch(k_run_rw<M, 4, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
         return launch(k_run_rw<M, 4, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
     })
 }

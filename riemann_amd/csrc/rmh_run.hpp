@@ -143,6 +143,14 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
     keep.record<NT>(run, ch, 0, c, g, active, th, lp);
     AdaptScale ad{0.0, 0.0, 1.0};
     if (ADAPT) ad.load(ch, c);
+    // AdaptScalepCN (randomwalk.py:104-119): rho <- tanh(rho / scale) before every proposal,
+    // a recursion on the chain's own rho (4th row of the adaptation state; NaN = not started);
+    // rho_c and with it the tile image keep their initial value, as in the reference
+    double rho = pr.rho;
+    if (PCN && ADAPT) {
+        const double aux = ch.adapt[3 * ch.ld + c];
+        rho = (aux != aux) ? pr.rho : aux;
+    }
 
     for (int64_t t = 0; t < run.T; ++t) {
         // the tile images never change, so without this fence LICM hoists their
@@ -174,16 +182,17 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
         double4_t acc[NT];
         double thp[S], lpp, dummy[S], parts[2], logq = 0.0;
         if (PCN) {
+            if (ADAPT) rho = tanh(rho / ad.scale);       // randomwalk.py:118
 #pragma unroll
-            for (int s = 0; s < S; ++s) thp[s] = pr.rho * th[s];
+            for (int s = 0; s < S; ++s) thp[s] = rho * th[s];
             T::pack(thp, acc);
             T::template mul_lower<LGLOBAL>(Limg + lane, xi, acc, ch.ks);   // image holds rho_c * L
             T::unpack(acc, thp);
             double ufw[S], urv[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                ufw[s] = thp[s] - pr.rho * th[s];        // randomwalk.py:95-96
-                urv[s] = th[s] - pr.rho * thp[s];
+                ufw[s] = thp[s] - rho * th[s];           // randomwalk.py:95-96
+                urv[s] = th[s] - rho * thp[s];
             }
             tri_apply<NT, false>(pr.Vtiles + lane, ufw, ch.ks);
             tri_apply<NT, false>(pr.Vtiles + lane, urv, ch.ks);
@@ -194,7 +203,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
                 sr += urv[s] * urv[s];
             }
             logq = -0.5 * (sum4(sf) - sum4(sr));         // :99-100
-        } else if (ADAPT) { // the chain's own adapted scale: theta + scale * (L xi), image unscaled
+        } else if (ADAPT && !PCN) { // the chain's own adapted scale: theta + scale * (L xi), image unscaled
 #pragma unroll
             for (int i = 0; i < NT; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
             T::template mul_lower<LGLOBAL>(Limg + lane, xi, acc, ch.ks);
@@ -249,6 +258,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
         T::store_state(ch.theta, ch.ld, c, g, th);
         if (g == 0) ch.logpost[c] = lp;
         if (ADAPT && g == 0) ad.store(ch, c);
+        if (PCN && ADAPT && g == 0) ch.adapt[3 * ch.ld + c] = rho;
         xo_store(ch.rng, ch.nslots, slot, rng);
     }
 }

@@ -85,3 +85,23 @@ class pCN(DeviceProposal):
         h = C.c_void_p()
         _lib.call("rmh_proposal_pcn_create", _lib.as_f64(self.L), self.Npars, float(rho), C.byref(h))
         self._h = h
+
+
+class AdaptScalepCN(AdaptScaleProposal, pCN):
+    """A preconditioned Crank-Nicolson proposal with an adaptive scaling parameter targeting
+    an acceptance rate of 0.25 (randomwalk.py:104-119).  As in the reference, before every
+    proposal ``rho = tanh(rho / scale)`` -- a recursion on the current ``rho``, not on
+    ``rho0`` -- while ``rho_c`` keeps its initial value.  Every chain carries its own ``rho``
+    and ``scale`` (arrays after ``run`` when the Sampler has several chains)."""
+
+    def __init__(self, C_, rho):
+        pCN.__init__(self, C_, rho)
+        self._init_adapt(0.25)
+        self.rho0 = self.rho
+
+    def _pull_adapt(self, state, single):
+        AdaptScaleProposal._pull_adapt(self, state, single)
+        aux = np.empty(state["N"])
+        _lib.call("rmh_state_get_adapt_aux", state["handle"], aux)
+        aux = np.where(np.isnan(aux), self.rho0, aux)
+        self.rho = float(aux[0]) if single else aux

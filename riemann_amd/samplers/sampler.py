@@ -154,6 +154,9 @@ class Sampler(object):
         ad = np.empty((self.Nchains, 3))
         _lib.call("rmh_state_get_adapt", self._state, ad)
         extra = {}
+        aux = np.empty(self.Nchains)
+        _lib.call("rmh_state_get_adapt_aux", self._state, aux)
+        extra["adapt_aux"] = aux
         if hasattr(self.proposal, "_adapt_cov_state"):      # AdaptCov*: the pooled accumulators
             extra["adapt_cov"] = self.proposal._adapt_cov_state()
         np.savez(path, theta=th, logpost=lp, rng=rng, adapt=ad, single=np.bool_(self._single), **extra)
@@ -169,6 +172,8 @@ class Sampler(object):
         _lib.call("rmh_state_set_theta", self._state, _lib.as_f64(z["theta"]))
         _lib.call("rmh_state_set_rng", self._state, np.ascontiguousarray(z["rng"], dtype=np.uint64))
         _lib.call("rmh_state_set_adapt", self._state, _lib.as_f64(z["adapt"]))
+        if "adapt_aux" in z:
+            _lib.call("rmh_state_set_adapt_aux", self._state, _lib.as_f64(z["adapt_aux"]))
         if "adapt_cov" in z and hasattr(self.proposal, "_adapt_cov_state"):
             st = _lib.as_f64(z["adapt_cov"])
             _lib.call("rmh_proposal_adapt_cov_set", self.proposal._h, st, float(st[0]) * self.Nchains)

@@ -405,6 +405,12 @@ def g10_pcn():
     r = run_reference(m2, lambda: pCN(np.eye(2), 0.8), np.ones((4, 2)), seed=101, T=64)
     save("g10_pcn_gauss2d", mu=np.zeros(2), C=0.1 * np.eye(2) + 0.9 * np.ones((2, 2)), Cprop=np.eye(2),
          rho=np.float64(0.8), **r)
+    # AdaptScalepCN (randomwalk.py:104-119): rho <- tanh(rho/scale) recursively, rho_c stale
+    from riemann.proposals.randomwalk import AdaptScalepCN
+    r = run_reference(m2, lambda: AdaptScalepCN(np.eye(2), 0.8), np.ones((4, 2)), seed=102, T=64,
+                      capture=lambda p: {"rho_final": np.float64(p.rho), "scale_final": np.float64(p.scale)})
+    save("g10_adaptscalepcn_gauss2d", mu=np.zeros(2), C=0.1 * np.eye(2) + 0.9 * np.ones((2, 2)),
+         Cprop=np.eye(2), rho=np.float64(0.8), **r)
 
 
 def g11_mixture():

@@ -1147,3 +1147,42 @@ def test_g14_adaptive_covariance_hmc_fixtures_and_many_chains(ra, orc):
     np.testing.assert_allclose(s._chain_thetas, ht, rtol=1e-7, atol=1e-10)
     np.testing.assert_allclose(p.C, orc.adaptcov_CL(stc, 24)[0], rtol=1e-8, atol=1e-14)
     assert 0.05 < acc.mean() < 0.99 and acc[:4].mean() > 0.5
+
+
+def test_g10_adaptive_scale_pcn(ra, orc, tmp_path):
+    """AdaptScalepCN: reference fixture, then many chains against the oracle, then a
+    checkpoint across the per-chain rho."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import AdaptScalepCN
+    z = load("g10_adaptscalepcn_gauss2d")
+    m = MultiGaussianDist(z["mu"], z["C"])
+    p = AdaptScalepCN(z["Cprop"], float(z["rho"]))
+    s = ra.Sampler(m, p, z["theta0"], seed=int(z["seed"]))
+    s.run(64)
+    check_run(z, s)
+    np.testing.assert_allclose(p.rho, z["rho_final"], rtol=1e-12)
+    np.testing.assert_allclose(p.scale, z["scale_final"], rtol=1e-12)
+    d, N, T = 40, 600, 30
+    g = np.random.default_rng(2)
+    A = g.standard_normal((d, d))
+    Ct = A @ A.T / d + 0.3 * np.eye(d)
+    th0 = g.standard_normal((N, d))
+    m = MultiGaussianDist(np.zeros(d), Ct)
+    p = AdaptScalepCN(0.1 * np.eye(d), 0.95)
+    s = ra.Sampler(m, p, th0, seed=8)
+    s.run(T)
+    om = orc.Gaussian(np.zeros(d), Ct)
+    th, st, ad, aux = th0.copy(), orc.rng_seed(8, N), orc.new_adapt_state(N), np.full(N, np.nan)
+    ht, hl, acc = orc.run(om, orc.set_adapt(orc.PCN(0.1 * np.eye(d), 0.95), 0.25), th, om.log_posterior(th),
+                          st, T, adapt=ad, aux=aux)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(p.rho, aux, rtol=1e-12)
+    s.checkpoint(str(tmp_path / "apcn.npz"))
+    s.run(10)
+    ref = s._chain_thetas.copy()
+    p2 = AdaptScalepCN(0.1 * np.eye(d), 0.95)
+    s2 = ra.Sampler(m, p2, th0, seed=0)
+    s2.restore(str(tmp_path / "apcn.npz"))
+    s2.run(10)
+    np.testing.assert_array_equal(s2._chain_thetas, ref)

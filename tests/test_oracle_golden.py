@@ -457,3 +457,17 @@ def test_g14_adaptive_covariance_hmc(name, adaptive):
         np.testing.assert_array_equal(acc[:, 0], z["accept"][:, c])
         np.testing.assert_allclose(ht[:, 0], z["thetas"][:, c], rtol=1e-8, atol=1e-12)
         np.testing.assert_allclose(hl[:, 0], z["logpost"][:, c], rtol=1e-8)
+
+
+def test_g10_adaptive_scale_pcn():
+    """AdaptScalepCN (randomwalk.py:104-119)."""
+    z = load("g10_adaptscalepcn_gauss2d")
+    model = orc.Gaussian(z["mu"], z["C"])
+    th = np.ascontiguousarray(z["theta0"]).copy()
+    N = th.shape[0]
+    st, ad, aux = orc.rng_seed(int(z["seed"]), N), orc.new_adapt_state(N), np.full(N, np.nan)
+    prop = orc.set_adapt(orc.PCN(z["Cprop"], float(z["rho"])), 0.25)
+    ht, hl, acc = orc.run(model, prop, th, model.log_posterior(th), st, 64, adapt=ad, aux=aux)
+    check_run(z, ht, hl, acc)
+    np.testing.assert_allclose(aux, z["rho_final"], rtol=1e-12)
+    np.testing.assert_allclose(ad[:, 2], z["scale_final"], rtol=1e-12)

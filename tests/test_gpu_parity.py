@@ -1186,3 +1186,25 @@ def test_g10_adaptive_scale_pcn(ra, orc, tmp_path):
     s2.restore(str(tmp_path / "apcn.npz"))
     s2.run(10)
     np.testing.assert_array_equal(s2._chain_thetas, ref)
+
+
+def test_adaptive_covariance_on_mixture_and_logistic_vs_oracle(ra, orc):
+    from riemann_amd.models import LogisticRegression, benchmarks as b
+    from riemann_amd.proposals import AdaptCovRandomWalk
+    from riemann_amd.workloads import logreg_data
+    g = np.random.default_rng(11)
+    X, y = logreg_data(300, 16, seed=3)
+    cases = [(b.benchmark_gauss2d_mix2_cross, orc.Mixture(MIX2D), 0.5 * np.eye(2), g.standard_normal((400, 2))),
+             (LogisticRegression(X, y, 100.0), orc.LogReg(X, y, 100.0), 0.01 * np.eye(16),
+              0.05 * g.standard_normal((300, 16)))]
+    for m, om, C0, th0 in cases:
+        d, N, T = th0.shape[1], th0.shape[0], 40
+        p = AdaptCovRandomWalk(C0, t_adapt=300, smooth_adapt=True)
+        s = ra.Sampler(m, p, th0, seed=17)
+        s.run(T)
+        th, st, stc = th0.copy(), orc.rng_seed(17, N), orc.new_adaptcov_state(C0)
+        ht, hl, acc = orc.run_adaptcov(om, orc.RandomWalk(C0), th, om.log_posterior(th), st, T, stc, C0,
+                                       t_adapt=300, smooth_adapt=True)
+        np.testing.assert_array_equal(s._chain_accept, acc)
+        np.testing.assert_allclose(s._chain_thetas, ht, rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(p.C, orc.adaptcov_CL(stc, d)[0], rtol=1e-9, atol=1e-15)

@@ -1401,6 +1401,7 @@ static hipError_t launch_rw_plain(rmh_model *m, rmh_proposal *p, const ChainArgs
     case kGauss: return launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
     case kMixture: return launch_mix_rw(m->NT, m->ma, ra, c, r, adapt, g_stream);
     case kLogReg: return launch_logreg_rw(m->NT, m->la, ra, c, r, adapt, g_stream);
+    case kChangepoint: return launch_cp_generic(m->k, m->ca, ra, c, r, adapt ? 1 : 0, g_stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -1489,11 +1490,7 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         return rc;
     }
     const bool adapt = p->adapt_target > 0;
-    if (adapt) {
-        if (m->kind == kChangepoint)
-            return fail(RMH_ERR_PARAM, "run: scale adaptation is not built for the changepoint kernel yet");
-        if ((rc = ensure_adapt(s))) return rc;
-    }
+    if (adapt && (rc = ensure_adapt(s))) return rc;
     ChainArgs c = chain_args(s);
     c.adapt = adapt ? s->adapt : nullptr;
     c.adapt_target = p->adapt_target;
@@ -1507,8 +1504,6 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
     if (K > 0) { // parallel tempering: the slots' inverse temperatures
         if (p->kind != kRW || adapt)
             return fail(RMH_ERR_PARAM, "run_pt: built for MetropolisRandomWalk within-chain moves only");
-        if (m->kind == kChangepoint)
-            return fail(RMH_ERR_PARAM, "run_pt: not built for the changepoint kernel");
         std::vector<double> b((size_t)s->ld, 1.0);
         const int used = (16 / K) * K;
         for (int64_t c0 = 0; c0 < s->ld; ++c0)
@@ -1528,8 +1523,8 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
         e = launch_big_gauss_rw(m->NT, m->ga, ra, c, r, g_stream);
     } else if (p->acov) {
-        if (K > 0 || p->kind == kPCN || p->nblk > 0 || m->kind == kChangepoint ||
-            (p->kind == kHMC && (adapt || m->kind == kMixture)))
+        if (K > 0 || p->kind == kPCN || p->nblk > 0 ||
+            (p->kind == kHMC && (adapt || m->kind == kMixture || m->kind == kChangepoint)))
             return fail(RMH_ERR_PARAM, "run: AdaptCov is built for the random walk (plain or with scale "
                                        "adaptation) and for HMC on the Gaussian, mixture (random walk) "
                                        "and logistic models");
@@ -1537,22 +1532,24 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         if ((rc = run_adaptcov(m, p, s, c, T, nburn, nthin, h, &launches))) return rc;
     } else if (K > 0) {
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
-        e = m->kind == kGauss    ? launch_gauss_pt(m->NT, m->ga, ra, c, r, g_stream)
-            : m->kind == kLogReg ? launch_logreg_rw(m->NT, m->la, ra, c, r, false, g_stream)
-                                 : launch_mix_rw(m->NT, m->ma, ra, c, r, false, g_stream);
+        e = m->kind == kGauss         ? launch_gauss_pt(m->NT, m->ga, ra, c, r, g_stream)
+            : m->kind == kLogReg      ? launch_logreg_rw(m->NT, m->la, ra, c, r, false, g_stream)
+            : m->kind == kChangepoint ? launch_cp_generic(m->k, m->ca, ra, c, r, 4, g_stream)
+                                      : launch_mix_rw(m->NT, m->ma, ra, c, r, false, g_stream);
     } else if (p->kind == kPCN) {
         RwArgs ra{p->d_Ltiles, p->d_V, p->rho};
-        if (m->kind == kChangepoint) return fail(RMH_ERR_PARAM, "run: pCN is not built for the changepoint kernel");
-        if (adapt && m->kind != kGauss)
-            return fail(RMH_ERR_PARAM, "run: AdaptScalepCN is built for the Gaussian model only");
-        e = m->kind == kGauss    ? launch_gauss_pcn(m->NT, m->ga, ra, c, r, adapt, g_stream)
-            : m->kind == kLogReg ? launch_logreg_pcn(m->NT, m->la, ra, c, r, g_stream)
-                                 : launch_mix_pcn(m->NT, m->ma, ra, c, r, g_stream);
+        if (adapt && m->kind != kGauss && m->kind != kChangepoint)
+            return fail(RMH_ERR_PARAM, "run: AdaptScalepCN is built for the Gaussian and changepoint models only");
+        e = m->kind == kGauss         ? launch_gauss_pcn(m->NT, m->ga, ra, c, r, adapt, g_stream)
+            : m->kind == kLogReg      ? launch_logreg_pcn(m->NT, m->la, ra, c, r, g_stream)
+            : m->kind == kChangepoint ? launch_cp_generic(m->k, m->ca, ra, c, r, adapt ? 3 : 2, g_stream)
+                                      : launch_mix_pcn(m->NT, m->ma, ra, c, r, g_stream);
     } else if (p->kind == kRW) {
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
         if (p->nblk > 0) {
             if (m->kind != kChangepoint || adapt)
-                return fail(RMH_ERR_PARAM, "run: block-mixture proposals are built for the changepoint model only");
+                return fail(RMH_ERR_PARAM, "run: block-mixture proposals are built for the changepoint model, "
+                                           "without scale adaptation");
             ra.nblk = p->nblk;
             for (int b = 0; b < 3; ++b) {
                 ra.blk_end[b] = p->blk_end[b];
@@ -1560,6 +1557,7 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
             }
         }
         if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
+        else if (m->kind == kChangepoint && adapt) e = launch_cp_generic(m->k, m->ca, ra, c, r, 1, g_stream);
         else if (m->kind == kChangepoint) e = launch_cp_rw(m->k, m->ca, ra, c, r, g_stream);
         else if (m->kind == kMixture) e = launch_mix_rw(m->NT, m->ma, ra, c, r, adapt, g_stream);
         else e = launch_logreg_rw(m->NT, m->la, ra, c, r, adapt, g_stream);

@@ -165,6 +165,10 @@ hipError_t launch_big_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, cons
                                const RunArgs &r, hipStream_t st);
 hipError_t launch_big_gauss_eval(int NT, const GaussArgs &m, const ChainArgs &c, double *lp_out,
                                  double *lprior_out, double *llik_out, hipStream_t st);
+// generic fused kernels over the changepoint policy (rmh_kernels_cp.hip): variant 0 plain,
+// 1 AdaptScale random walk, 2 pCN, 3 AdaptScalepCN, 4 parallel tempering
+hipError_t launch_cp_generic(int k, const CpArgs &m, const RwArgs &p, const ChainArgs &c,
+                             const RunArgs &r, int variant, hipStream_t st);
 hipError_t launch_rng_seed(uint64_t *rng, int64_t ld, uint64_t seed, uint64_t chain0,
                            hipStream_t st);
 hipError_t launch_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const double *icdf,

@@ -13,8 +13,7 @@
 //   likelihood lane g takes the data points i = g (mod 4); x, y sit in LDS
 // and partial sums meet in a 2-step xor butterfly.  HBM-bound on paper (104 B
 // per recorded sample), instruction-issue bound in practice.
-#include "rmh_internal.hpp"
-#include "rmh_mfma.hpp"
+#include "rmh_run.hpp"
 
 namespace rmh {
 
@@ -125,6 +124,47 @@ struct CpModel {
         double logL = -0.5 * ((ss + m.n * log_full(sig2)) + m.nlog2pi); // :118-121
         if (logL != logL) logL = -__builtin_huge_val();                 // :124-125
         return logL;
+    }
+};
+
+// The changepoint model as a Model policy of the generic fused kernels (rmh_run.hpp): slower
+// than k_cp_rw below (256-thread workgroups, the chain's parameters gathered from the tile
+// layout for every evaluation) but it brings everything those kernels can do -- scale
+// adaptation, pCN, covariance adaptation, parallel tempering -- to this model.
+constexpr int kCpPolicyMaxN = 1024; // data points the policy's LDS area holds
+
+template <int KC>
+struct CpPolicy {
+    using Args = CpArgs;
+    using CM = CpModel<KC>;
+    static constexpr int D = CM::D, NT = (D + 15) / 16;
+    using T = Tile<NT>;
+    static constexpr int S = T::S;
+
+    static constexpr __host__ __device__ size_t lds_doubles(bool) { return 2 * kCpPolicyMaxN; }
+    static RMH_DEV void setup(double *lds, const Args &m, bool)
+    {
+        for (int i = threadIdx.x; i < 2 * m.n; i += blockDim.x) lds[i] = m.xy[i];
+    }
+
+    template <bool GRAD, bool VALUE = true>
+    static RMH_DEV void eval(const double *lds, const Args &m, bool, int lane, const double (&th)[S],
+                             double &lp, double (&grad)[S], double (&parts)[2])
+    {
+        static_assert(!GRAD, "the changepoint model has no gradient");
+        const int cl = lane & 15, g = lane >> 4;
+        double full[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) full[j] = __shfl(th[j >> 2], cl + 16 * (j & 3));
+        const double logP = CM::log_prior(m, full, g);
+        double logL = -__builtin_huge_val();
+        // the sorted-cpx likelihood is valid wherever the prior is finite; elsewhere the
+        // posterior is -inf whatever it returns
+        if (__any(logP > -__builtin_huge_val())) logL = CM::template log_lik<true>(lds, m, full, g);
+        lp = combine_post(logP, logL);
+        parts[0] = logP;
+        parts[1] = logL;
+        (void)grad;
     }
 };
 
@@ -309,6 +349,40 @@ hipError_t launch_cp_rw(int k, const CpArgs &m, const RwArgs &p, const ChainArgs
                         const RunArgs &r, hipStream_t st)
 {
     RMH_CP_DISPATCH(cp_rw_launch, m, p, c, r, st)
+}
+
+// the generic fused kernels over the changepoint policy: variant 1 = AdaptScale random walk,
+// 2 = pCN, 3 = AdaptScalepCN, 4 = parallel tempering, 0 = plain (used by the covariance adaptation)
+template <int KC>
+static hipError_t cp_generic_launch(const CpArgs &m, const RwArgs &p, const ChainArgs &c,
+                                    const RunArgs &r, int variant, hipStream_t st)
+{
+    using M = CpPolicy<KC>;
+    if (m.n > kCpPolicyMaxN) return hipErrorInvalidValue;
+    const size_t lds = sizeof(double) * (tri_tiles(M::NT) * 64 + M::lds_doubles(false) + kIcdfDoubles);
+    const dim3 grid((unsigned)((c.nblocks + 3) / 4)), block(256);
+    hipError_t e = hipSuccess;
+#define RMH_CP_GEN(...)                                                                          \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_run_rw<M, 4, __VA_ARGS__>),         \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+    if (e != hipSuccess) return e;                                                               \
+    hipLaunchKernelGGL((k_run_rw<M, 4, __VA_ARGS__>), grid, block, lds, st, m, p, c, r)
+    switch (variant) {
+    case 0: RMH_CP_GEN(false, false, false); break;
+    case 1: RMH_CP_GEN(true, false, false); break;
+    case 2: RMH_CP_GEN(false, true, false); break;
+    case 3: RMH_CP_GEN(true, true, false); break;
+    case 4: RMH_CP_GEN(false, false, true); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef RMH_CP_GEN
+    return hipGetLastError();
+}
+
+hipError_t launch_cp_generic(int k, const CpArgs &m, const RwArgs &p, const ChainArgs &c,
+                             const RunArgs &r, int variant, hipStream_t st)
+{
+    RMH_CP_DISPATCH(cp_generic_launch, m, p, c, r, variant, st)
 }
 
 hipError_t launch_cp_eval(int k, const CpArgs &m, const ChainArgs &c, double *lprior,

@@ -1208,3 +1208,62 @@ def test_adaptive_covariance_on_mixture_and_logistic_vs_oracle(ra, orc):
         np.testing.assert_array_equal(s._chain_accept, acc)
         np.testing.assert_allclose(s._chain_thetas, ht, rtol=1e-8, atol=1e-11)
         np.testing.assert_allclose(p.C, orc.adaptcov_CL(stc, d)[0], rtol=1e-9, atol=1e-15)
+
+
+def test_changepoint_with_the_generic_kernels_vs_oracle(ra, orc):
+    """Scale adaptation, pCN, AdaptScalepCN, covariance adaptation and parallel tempering on the
+    changepoint model (the model as a policy of the generic fused kernels)."""
+    from riemann_amd import workloads as W
+    from riemann_amd.models import ChangepointRegression1D
+    from riemann_amd.proposals import (AdaptCovRandomWalk, AdaptScalepCN, AdaptScaleRandomWalk,
+                                       MetropolisRandomWalk, pCN)
+    from riemann_amd.samplers import PTSampler
+    x, y, truth, cdiag = W.changepoint_data()
+    k, d, N, T = 5, 12, 700, 40
+    m = ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=k)
+    om = orc.Changepoint(x, y, k, 1.0, 3.0, 5.0, 1.0, 1.0)
+    g = np.random.default_rng(9)
+    th0 = truth + 0.01 * g.standard_normal((N, d))
+    th0[:, :k] = np.sort(th0[:, :k], axis=1)
+    th0[5, 0], th0[5, 1] = th0[5, 1], th0[5, 0]              # one chain starts outside the support
+    Cp = 0.02 * np.diag(cdiag)
+
+    def compare(s, ht, hl, acc, rtol=RTOL):
+        np.testing.assert_array_equal(s._chain_accept, acc)
+        np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+        assert np.array_equal(np.isinf(s._chain_logpost), np.isinf(hl))
+        fin = np.isfinite(hl)
+        np.testing.assert_allclose(s._chain_logpost[fin], hl[fin], rtol=rtol)
+
+    s = ra.Sampler(m, AdaptScaleRandomWalk(Cp), th0, seed=1)
+    s.run(T)
+    th, st, ad = th0.copy(), orc.rng_seed(1, N), orc.new_adapt_state(N)
+    compare(s, *orc.run(om, orc.set_adapt(orc.RandomWalk(Cp), 0.25), th, om.log_posterior(th), st, T, adapt=ad))
+    s = ra.Sampler(m, pCN(Cp, 0.999), th0, seed=2)
+    s.run(T)
+    compare(s, *oracle_run(orc, om, orc.PCN(Cp, 0.999), th0, 2, T))
+    s = ra.Sampler(m, AdaptScalepCN(Cp, 0.999), th0, seed=3)
+    s.run(T)
+    th, st, ad, aux = th0.copy(), orc.rng_seed(3, N), orc.new_adapt_state(N), np.full(N, np.nan)
+    compare(s, *orc.run(om, orc.set_adapt(orc.PCN(Cp, 0.999), 0.25), th, om.log_posterior(th), st, T, adapt=ad, aux=aux))
+    good = np.delete(th0, 5, axis=0)                          # pooled moments need finite chains
+    p = AdaptCovRandomWalk(Cp, t_adapt=5000, smooth_adapt=True)
+    s = ra.Sampler(m, p, good, seed=4)
+    s.run(T)
+    th, st, stc = good.copy(), orc.rng_seed(4, N - 1), orc.new_adaptcov_state(Cp)
+    # the pooled covariance (matrix-core sums vs the oracle's loops) feeds back into the states at
+    # the 1e-10 level, and log L ~ sum r^2 / sig^2 with sig = 0.1 magnifies that: contract tolerance
+    compare(s, *orc.run_adaptcov(om, orc.RandomWalk(Cp), th, om.log_posterior(th), st, T, stc, Cp,
+                                 t_adapt=5000, smooth_adapt=True), rtol=1e-6)
+    # variances of 1e-5 around values of 2: the one-pass covariance cancels ~5 digits
+    np.testing.assert_allclose(p.C, orc.adaptcov_CL(stc, d)[0], rtol=1e-5, atol=1e-12)
+    K, Ne, betas = 4, 150, 0.5 ** np.arange(4)
+    pt = PTSampler(m, MetropolisRandomWalk(Cp), th0[:Ne], betas=betas, Pswap=0.3, seed=5)
+    pt.run(T)
+    S, idx = orc.pt_slots(Ne, K)
+    slots = np.zeros((S, d))
+    slots[:] = th0[0]
+    slots[idx] = th0[:Ne, None, :]
+    ht, hl, code, _ = orc.run_pt(om, orc.RandomWalk(Cp), slots, orc.rng_seed(5, S), T, betas, 0.3)
+    np.testing.assert_array_equal(pt._host_codes, code[:, idx])
+    np.testing.assert_allclose(pt._host_thetas, ht[:, idx], rtol=RTOL, atol=1e-12)

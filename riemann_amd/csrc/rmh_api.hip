@@ -1538,12 +1538,10 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
                                       : launch_mix_rw(m->NT, m->ma, ra, c, r, false, g_stream);
     } else if (p->kind == kPCN) {
         RwArgs ra{p->d_Ltiles, p->d_V, p->rho};
-        if (adapt && m->kind != kGauss && m->kind != kChangepoint)
-            return fail(RMH_ERR_PARAM, "run: AdaptScalepCN is built for the Gaussian and changepoint models only");
         e = m->kind == kGauss         ? launch_gauss_pcn(m->NT, m->ga, ra, c, r, adapt, g_stream)
-            : m->kind == kLogReg      ? launch_logreg_pcn(m->NT, m->la, ra, c, r, g_stream)
+            : m->kind == kLogReg      ? launch_logreg_pcn(m->NT, m->la, ra, c, r, adapt, g_stream)
             : m->kind == kChangepoint ? launch_cp_generic(m->k, m->ca, ra, c, r, adapt ? 3 : 2, g_stream)
-                                      : launch_mix_pcn(m->NT, m->ma, ra, c, r, g_stream);
+                                      : launch_mix_pcn(m->NT, m->ma, ra, c, r, adapt, g_stream);
     } else if (p->kind == kRW) {
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
         if (p->nblk > 0) {

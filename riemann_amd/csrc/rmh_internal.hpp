@@ -128,9 +128,9 @@ hipError_t launch_mix_eval(int NT, const MixArgs &m, const ChainArgs &c, double 
 hipError_t launch_mix_rw(int NT, const MixArgs &m, const RwArgs &p, const ChainArgs &c,
                          const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_mix_pcn(int NT, const MixArgs &m, const RwArgs &p, const ChainArgs &c,
-                          const RunArgs &r, hipStream_t st);
+                          const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_logreg_pcn(int NT, const LogRegArgs &m, const RwArgs &p, const ChainArgs &c,
-                             const RunArgs &r, hipStream_t st);
+                             const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_gauss_pcn(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                             const RunArgs &r, bool adapt, hipStream_t st);
 // p.chM != null selects the mass-matrix variant

@@ -99,11 +99,12 @@ hipError_t launch_mix_rw(int NT, const MixArgs &m, const RwArgs &p, const ChainA
 }
 
 hipError_t launch_mix_pcn(int NT, const MixArgs &m, const RwArgs &p, const ChainArgs &c,
-                          const RunArgs &r, hipStream_t st)
+                          const RunArgs &r, bool adapt, hipStream_t st)
 {
     RMH_NT_DISPATCH(NT, {
         using M = MixModel<kNT>;
         const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + kIcdfDoubles);
+        if (adapt) return launch(k_run_rw<M, 4, true, true, false>, c.nblocks, 4, lds, st, m, p, c, r);
         return launch(k_run_rw<M, 4, false, true, false>, c.nblocks, 4, lds, st, m, p, c, r);
     })
 }
@@ -190,11 +191,12 @@ hipError_t launch_logreg_rw(int NT, const LogRegArgs &m, const RwArgs &p, const 
 }
 
 hipError_t launch_logreg_pcn(int NT, const LogRegArgs &m, const RwArgs &p, const ChainArgs &c,
-                             const RunArgs &r, hipStream_t st)
+                             const RunArgs &r, bool adapt, hipStream_t st)
 {
     RMH_NT_DISPATCH(NT, {
         using M = LogRegModel<kNT>;
         const size_t lds = sizeof(double) * (M::lds_doubles(false) + kIcdfDoubles);
+        if (adapt) return launch(k_run_rw<M, 4, true, true, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
         return launch(k_run_rw<M, 4, false, true, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
     })
 }

@@ -907,7 +907,7 @@ def test_logreg_random_walk_plain_adaptive_and_tempered(ra, orc, n, d):
 def test_pcn_and_adaptive_scale_on_mixture_and_logistic(ra, orc):
     """The remaining model x proposal cells of the random-walk family, against the oracle."""
     from riemann_amd.models import LogisticRegression, benchmarks as b
-    from riemann_amd.proposals import AdaptScaleRandomWalk, pCN
+    from riemann_amd.proposals import AdaptScalepCN, AdaptScaleRandomWalk, pCN
     from riemann_amd.workloads import logreg_data
     T = 40
     th0 = np.random.default_rng(2).standard_normal((300, 2))

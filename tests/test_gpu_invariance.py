@@ -112,3 +112,19 @@ def test_mixture_target_is_invariant_under_random_walk_and_tempering():
         same_moments(pt.samplers[i].current_state()[0], exact(Ne))
     assert (pt._chain_codes == 3).mean() > 0.2   # and every swap between equals is accepted
     assert (pt._chain_codes == 2).sum() == 0
+
+
+def test_pooled_covariance_adaptation_finds_the_target_covariance(target):
+    """AdaptCovRandomWalk from a poor isotropic start: the pooled history covariance (65 536
+    chains x 100 states, matrix-core moment kernel) reproduces the target's, and the chains,
+    started from the target, are still distributed as the target afterwards."""
+    ra, m, mu, Ct, Lt, g = target
+    from riemann_amd.proposals import AdaptCovRandomWalk
+    th0 = mu + g.standard_normal((N, D)) @ Lt.T
+    p = AdaptCovRandomWalk(0.01 * np.eye(D), t_adapt=10, smooth_adapt=True, exact_squares=True)
+    s = ra.Sampler(m, p, th0, seed=21)
+    s.run(100, record=False)
+    est = p.C * D ** 0.4                        # C = Cs / d^0.4 (adaptive.py:101), prior weight negligible
+    assert np.abs(est - Ct).max() < 0.02 * np.abs(Ct).max()
+    np.testing.assert_allclose(p._SX / (100 * N), mu, atol=0.02)
+    moments_ok(s.current_state()[0], mu, Ct)

@@ -16,17 +16,30 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from riemann_amd import Sampler                                         # noqa: E402
 from riemann_amd import diagnostics                                      # noqa: E402
 from riemann_amd.models.benchmarks import benchmark_gauss2d_corr         # noqa: E402
-from riemann_amd.proposals.hamiltonian import AdaptScaleHMC, VanillaHMC  # noqa: E402
-from riemann_amd.proposals.randomwalk import AdaptScaleRandomWalk, MetropolisRandomWalk  # noqa: E402
+from riemann_amd.proposals.hamiltonian import (AdaptCovHMC, AdaptScaleCovHMC, AdaptScaleHMC,  # noqa: E402
+                                                VanillaHMC)
+from riemann_amd.proposals.randomwalk import (AdaptCovRandomWalk, AdaptScaleCovRandomWalk,    # noqa: E402
+                                              AdaptScalepCN, AdaptScaleRandomWalk,
+                                              MetropolisRandomWalk, pCN)
 
 
 def test_sampling_gauss2d(nchains=4096):
     model = benchmark_gauss2d_corr
     grad = model.grad_log_likelihood
+    C0 = 0.0001 * np.eye(2)
+    # the nine proposals examples/test_randomwalk.py:23-37 builds (it samples with the last one only)
     for name, proposal in (("MetropolisRandomWalk", MetropolisRandomWalk(np.eye(2))),
-                           ("AdaptScaleRandomWalk", AdaptScaleRandomWalk(np.eye(2))),
+                           ("AdaptCovRandomWalk", AdaptCovRandomWalk(C0, t_adapt=100, smooth_adapt=False)),
+                           ("AdaptScaleRandomWalk", AdaptScaleRandomWalk(C0)),
+                           ("AdaptScaleCovRandomWalk", AdaptScaleCovRandomWalk(C0, t_adapt=0, smooth_adapt=False)),
+                           ("pCN(I, 0.5)", pCN(np.eye(2), 0.5)),
+                           ("AdaptScalepCN(I, 0.5)", AdaptScalepCN(np.eye(2), 0.5)),
                            ("VanillaHMC(0.1, 5)", VanillaHMC(0.1, 5, grad)),
-                           ("AdaptScaleHMC(0.1, 5)", AdaptScaleHMC(0.1, 5, grad))):
+                           ("AdaptScaleHMC(0.1, 5)", AdaptScaleHMC(0.1, 5, grad)),
+                           ("AdaptCovHMC(0.1, 5)", AdaptCovHMC(0.1, 5, grad, np.eye(2), t_adapt=100,
+                                                               smooth_adapt=True)),
+                           ("AdaptScaleCovHMC(0.1, 5)", AdaptScaleCovHMC(0.1, 5, grad, np.eye(2), t_adapt=100,
+                                                                         smooth_adapt=True))):
         sampler = Sampler(model, proposal, np.ones((nchains, 2)), seed=0)
         sampler.run(10000, 1000, 1)
         chain = sampler._chain_thetas                       # (9001, nchains, 2)

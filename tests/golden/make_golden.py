@@ -639,6 +639,25 @@ def g15_gauss_big_d():
     save("g15_gauss200d_rw", rng_seed_for_model=np.int64(15), **r)
 
 
+def g16_reference_example():
+    """The run of the reference's own smoke script, examples/test_randomwalk.py:34-40:
+    AdaptScaleCovHMC(0.1, 5, grad, I, t_adapt=100, smooth_adapt=True) with scale = 1.0 on
+    benchmark_gauss2d_corr from theta0 = ones(2), run(10000, 1000, 1) -- here on the injected
+    stream (the script itself is unseeded)."""
+    from riemann.proposals.hamiltonian import AdaptScaleCovHMC
+    m2 = rbench.benchmark_gauss2d_corr
+
+    def make():
+        p = AdaptScaleCovHMC(0.1, 5, m2.grad_log_likelihood, np.eye(2), t_adapt=100, smooth_adapt=True)
+        p.scale = 1.0
+        return p
+    r = run_reference(m2, make, np.ones((1, 2)), seed=160, T=10000, runs=[(10000, 1000, 1)],
+                      capture=lambda p: {"scale_final": np.float64(p.scale), "Naccepts": np.int64(p.Naccepts)})
+    r.pop("xi")
+    r.pop("u")
+    save("g16_example_test_randomwalk", mu=np.zeros(2), C=0.1 * np.eye(2) + 0.9 * np.ones((2, 2)), **r)
+
+
 class BlockReplay:
     """Feeds one chain's draws to the reference's ChangepointRegression1DProp + Sampler:
     the uniforms asked for inside ``propose`` (riemann/test_changepoint.py:47-51) are the
@@ -767,3 +786,4 @@ if __name__ == "__main__":
     g13_changepoint_block_proposal()
     g14_adapt_cov()
     g15_gauss_big_d()
+    g16_reference_example()

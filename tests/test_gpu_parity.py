@@ -1267,3 +1267,22 @@ def test_changepoint_with_the_generic_kernels_vs_oracle(ra, orc):
     ht, hl, code, _ = orc.run_pt(om, orc.RandomWalk(Cp), slots, orc.rng_seed(5, S), T, betas, 0.3)
     np.testing.assert_array_equal(pt._host_codes, code[:, idx])
     np.testing.assert_allclose(pt._host_thetas, ht[:, idx], rtol=RTOL, atol=1e-12)
+
+
+def test_g16_the_reference_example_run(ra):
+    """The reference's smoke script, examples/test_randomwalk.py:34-40, on the device: the same
+    10 000 steps of AdaptScaleCovHMC with burn-in 1000, state for state."""
+    from riemann_amd.models.benchmarks import benchmark_gauss2d_corr
+    from riemann_amd.proposals import AdaptScaleCovHMC
+    z = load("g16_example_test_randomwalk")
+    proposal = AdaptScaleCovHMC(0.1, 5, benchmark_gauss2d_corr.grad_log_likelihood, np.eye(2),
+                                t_adapt=100, smooth_adapt=True)
+    proposal.scale = 1.0
+    sampler = ra.Sampler(benchmark_gauss2d_corr, proposal, np.ones(2), seed=int(z["seed"]))
+    sampler.run(10000, 1000, 1)
+    chain = np.array(sampler._chain_thetas)
+    assert chain.shape == (9001, 2)
+    np.testing.assert_allclose(chain, z["thetas"][:, 0], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(sampler._chain_logpost, z["logpost"][:, 0], rtol=1e-7, atol=1e-10)
+    assert proposal.Naccepts == z["Naccepts"][0]
+    np.testing.assert_allclose(proposal.scale, z["scale_final"][0], rtol=1e-10)

@@ -471,3 +471,17 @@ def test_g10_adaptive_scale_pcn():
     check_run(z, ht, hl, acc)
     np.testing.assert_allclose(aux, z["rho_final"], rtol=1e-12)
     np.testing.assert_allclose(ad[:, 2], z["scale_final"], rtol=1e-12)
+
+
+def test_g16_the_reference_example_run():
+    """examples/test_randomwalk.py:34-40 end to end: 10 000 adaptive-HMC steps, burn-in 1000."""
+    z = load("g16_example_test_randomwalk")
+    model = orc.Gaussian(z["mu"], z["C"])
+    th = np.ascontiguousarray(z["theta0"]).copy()
+    st, ad = orc.rng_seed(int(z["seed"]), 1), orc.new_adapt_state(1)
+    prop = orc.set_adapt(orc.HMC(0.1, 5, 2, M=np.eye(2)), 0.75)
+    ht, hl, acc = orc.run(model, prop, th, model.log_posterior(th), st, 10000, adapt=ad)
+    np.testing.assert_allclose(ht[1000:], z["thetas"], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(hl[1000:], z["logpost"], rtol=1e-7, atol=1e-10)
+    assert ad[0, 1] == z["Naccepts"][0]
+    np.testing.assert_allclose(ad[0, 2], z["scale_final"][0], rtol=1e-10)

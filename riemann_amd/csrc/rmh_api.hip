@@ -1422,6 +1422,10 @@ static int run_adaptcov(rmh_model *m, rmh_proposal *p, rmh_state *s, const Chain
         RMH_HIP(hipMemsetAsync(s->sc_theta, 0, (size_t)(kAcovChunk + 1) * rows * ld * sizeof(double), g_stream));
     }
     if (!p->d_acov_partial && (rc = dev_alloc(&p->d_acov_partial, (size_t)kAcovWGs * acov_ntri(p) * 256))) return rc;
+    if (T == 0 && h && nburn == 0) { // run(0): the history is the state on entry (sampler.py:49-50)
+        RMH_HIP(hipMemcpyAsync(h->thetas, s->theta, (size_t)rows * ld * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
+        RMH_HIP(hipMemcpyAsync(h->logpost, s->logpost, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
+    }
     int64_t done = 0;
     while (done < T) {
         int64_t seg = std::min<int64_t>(T - done, kAcovChunk);

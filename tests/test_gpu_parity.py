@@ -1286,3 +1286,19 @@ def test_g16_the_reference_example_run(ra):
     np.testing.assert_allclose(sampler._chain_logpost, z["logpost"][:, 0], rtol=1e-7, atol=1e-10)
     assert proposal.Naccepts == z["Naccepts"][0]
     np.testing.assert_allclose(proposal.scale, z["scale_final"][0], rtol=1e-10)
+
+
+def test_adaptive_covariance_run_of_zero_steps(ra):
+    """run(0) with a covariance-adaptive proposal keeps the state on entry (found by
+    tools/fuzz_vs_oracle.py: the stretch loop never ran, so entry 0 was never written)."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import AdaptCovRandomWalk
+    th0 = np.random.default_rng(1).standard_normal((17, 15))
+    m = MultiGaussianDist(np.zeros(15), np.eye(15))
+    s = ra.Sampler(m, AdaptCovRandomWalk(0.1 * np.eye(15), t_adapt=10, smooth_adapt=True), th0, seed=1)
+    s.run(0, 0, 2)
+    np.testing.assert_array_equal(s._chain_thetas, th0[None])
+    np.testing.assert_allclose(s._chain_logpost[0], m.log_posterior(th0), rtol=RTOL)
+    s.run(3)
+    assert s._chain_thetas.shape == (4, 17, 15)
+    np.testing.assert_array_equal(s._chain_thetas[0], th0)

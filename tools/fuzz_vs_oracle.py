@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Randomised differential test: random (model, proposal, d, N, T, Nburn, Nthin) configurations on
+the device against the CPU oracle.  Test infrastructure (uses oracle/).   python tools/fuzz_vs_oracle.py [n] [seed]"""
+import os
+import sys
+import traceback
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import riemann_amd as ra                                                     # noqa: E402
+from oracle import oracle as orc                                              # noqa: E402
+from riemann_amd.models import LogisticRegression, MultiGaussianDist         # noqa: E402
+from riemann_amd.models.benchmarks import MixtureDist                        # noqa: E402
+from riemann_amd import proposals as P                                        # noqa: E402
+from riemann_amd.samplers import PTSampler                                    # noqa: E402
+
+
+def spd(g, d, lo=0.3):
+    A = g.standard_normal((d, d))
+    return A @ A.T / d + lo * np.eye(d)
+
+
+def one(g, it):
+    kind = g.choice(["gauss", "gauss", "logreg", "mix"])
+    dmax = {"gauss": 112, "logreg": 112, "mix": 40}[kind]
+    d = int(g.choice([1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 111, 112, int(g.integers(1, 113))]))
+    d = min(d, dmax)
+    N = int(g.choice([1, 2, 15, 16, 17, 63, 64, 65, 100, int(g.integers(1, 300))]))
+    T = int(g.integers(0, 14))
+    nb = int(g.integers(0, T + 2))
+    nt = int(g.integers(1, 4))
+    th0 = 0.3 * g.standard_normal((N, d))
+    if kind == "gauss":
+        mu, Ct = g.standard_normal(d), spd(g, d)
+        m, om = MultiGaussianDist(mu, Ct), orc.Gaussian(mu, Ct)
+        th0 = th0 + mu
+    elif kind == "logreg":
+        n = int(g.choice([1, 31, 32, 33, 100]))
+        X, y = g.standard_normal((n, d)) / np.sqrt(d), (g.uniform(size=n) < 0.5).astype(float)
+        m, om = LogisticRegression(X, y, 10.0), orc.LogReg(X, y, 10.0)
+    else:
+        comps = [(float(g.uniform(0.2, 1)), g.standard_normal(d), spd(g, d)) for _ in range(int(g.integers(1, 4)))]
+        m = MixtureDist([(w, MultiGaussianDist(mu, C)) for w, mu, C in comps])
+        om = orc.Mixture(comps)
+    Cp = (0.5 / d) * spd(g, d)
+    props = ["rw", "arw", "pcn", "apcn", "acov", "pt"]
+    if kind != "mix":
+        props += ["hmc", "mala", "hmcm", "ahmc"]
+    pk = str(g.choice(props))
+    desc = "%s d=%d N=%d T=%d nb=%d nt=%d %s" % (kind, d, N, T, nb, nt, pk)
+    seed = int(g.integers(0, 2 ** 31))
+    ad = aux = None
+    th, st = th0.copy(), orc.rng_seed(seed, N)
+    if pk == "pt":
+        K = int(g.integers(1, 7))
+        betas = np.sort(g.uniform(0.05, 1.0, size=K))[::-1].copy()
+        pt = PTSampler(m, P.MetropolisRandomWalk(Cp), th0, betas=betas, Pswap=0.3, seed=seed)
+        pt.run(T)
+        S, idx = orc.pt_slots(N, K)
+        slots = np.zeros((S, d))
+        slots[:] = th0[0]
+        slots[idx] = th0[:, None, :]
+        ht, hl, code, _ = orc.run_pt(om, orc.RandomWalk(Cp), slots, orc.rng_seed(seed, S), T, betas, 0.3)
+        assert np.array_equal(pt._host_codes, code[:, idx]), desc + " codes"
+        np.testing.assert_allclose(pt._host_thetas, ht[:, idx], rtol=1e-8, atol=1e-11, err_msg=desc)
+        return desc
+    if pk == "rw":
+        p, op = P.MetropolisRandomWalk(Cp), orc.RandomWalk(Cp)
+    elif pk == "arw":
+        p, op, ad = P.AdaptScaleRandomWalk(Cp), orc.set_adapt(orc.RandomWalk(Cp), 0.25), orc.new_adapt_state(N)
+    elif pk == "pcn":
+        p, op = P.pCN(Cp, 0.9), orc.PCN(Cp, 0.9)
+    elif pk == "apcn":
+        p, op = P.AdaptScalepCN(Cp, 0.9), orc.set_adapt(orc.PCN(Cp, 0.9), 0.25)
+        ad, aux = orc.new_adapt_state(N), np.full(N, np.nan)
+    elif pk == "hmc":
+        L = int(g.integers(1, 5))
+        p, op = P.VanillaHMC(0.2, L, m), orc.HMC(0.2, L, d)
+    elif pk == "mala":
+        p, op = P.MALA(0.2, m), orc.HMC(0.2, 1, d)
+    elif pk == "hmcm":
+        Mm = spd(g, d)
+        p, op = P.VanillaHMC(0.2, 3, m, M=Mm), orc.HMC(0.2, 3, d, M=Mm)
+    elif pk == "ahmc":
+        p, op, ad = P.AdaptScaleHMC(0.2, 2, m), orc.set_adapt(orc.HMC(0.2, 2, d), 0.75), orc.new_adapt_state(N)
+    elif pk == "acov":
+        if d > 111:
+            return desc + " (skipped)"
+        p = P.AdaptCovRandomWalk(Cp, t_adapt=50, smooth_adapt=True)
+        s = ra.Sampler(m, p, th0, seed=seed)
+        s.run(T, nb, nt)
+        stc = orc.new_adaptcov_state(Cp)
+        ht, hl, acc = orc.run_adaptcov(om, orc.RandomWalk(Cp), th, om.log_posterior(th), st, T, stc, Cp,
+                                       t_adapt=50, smooth_adapt=True)
+        assert np.array_equal(s._chain_accept, acc), desc + " accept"
+        np.testing.assert_allclose(s._chain_thetas, ht[nb::nt], rtol=1e-7, atol=1e-10, err_msg=desc)
+        return desc
+    s = ra.Sampler(m, p, th0, seed=seed)
+    s.run(T, nb, nt)
+    ht, hl, acc = orc.run(om, op, th, om.log_posterior(th), st, T, adapt=ad, aux=aux)
+    assert np.array_equal(s._chain_accept, acc), desc + " accept"
+    np.testing.assert_allclose(s._chain_thetas, ht[nb::nt], rtol=1e-8, atol=1e-11, err_msg=desc)
+    ref = hl[nb::nt]
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(s._chain_logpost[fin], ref[fin], rtol=1e-8, atol=1e-10, err_msg=desc)
+    return desc
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    g = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    bad = 0
+    for it in range(n):
+        try:
+            d = one(g, it)
+            print("ok  ", d, flush=True)
+        except Exception as e:           # keep going: collect every failing configuration
+            bad += 1
+            print("FAIL", repr(e)[:300], flush=True)
+            traceback.print_exc(limit=2)
+    print("%d configurations, %d failed" % (n, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import riemann_amd as ra                                                     # noqa: E402
 from oracle import oracle as orc                                              # noqa: E402
-from riemann_amd.models import LogisticRegression, MultiGaussianDist         # noqa: E402
+from riemann_amd.models import ChangepointRegression1D, LogisticRegression, MultiGaussianDist  # noqa: E402
 from riemann_amd.models.benchmarks import MixtureDist                        # noqa: E402
 from riemann_amd import proposals as P                                        # noqa: E402
 from riemann_amd.samplers import PTSampler                                    # noqa: E402
@@ -22,16 +22,32 @@ def spd(g, d, lo=0.3):
 
 
 def one(g, it):
-    kind = g.choice(["gauss", "gauss", "logreg", "mix"])
-    dmax = {"gauss": 112, "logreg": 112, "mix": 40}[kind]
+    kind = g.choice(["gauss", "gauss", "logreg", "mix", "cp", "bigd"])
+    dmax = {"gauss": 112, "logreg": 112, "mix": 40, "cp": 18, "bigd": 896}[kind]
     d = int(g.choice([1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 111, 112, int(g.integers(1, 113))]))
     d = min(d, dmax)
+    if kind == "bigd":
+        d = int(g.choice([113, 127, 128, 129, 224, 225, 300, 448, 449, int(g.integers(113, 600))]))
+    if kind == "cp":
+        kc = int(g.integers(1, 9))
+        d = 2 * kc + 2
     N = int(g.choice([1, 2, 15, 16, 17, 63, 64, 65, 100, int(g.integers(1, 300))]))
     T = int(g.integers(0, 14))
     nb = int(g.integers(0, T + 2))
     nt = int(g.integers(1, 4))
     th0 = 0.3 * g.standard_normal((N, d))
-    if kind == "gauss":
+    if kind == "cp":
+        n = int(g.choice([4, 25, 100, 101]))
+        x = np.sort(g.uniform(1.0, 3.0, size=n))
+        y = g.uniform(1.0, 3.0, size=n)
+        al, be = (1.0, 1.0) if g.uniform() < 0.5 else (2.5, 1.5)
+        m = ChangepointRegression1D(x, y, 1.0, 3.0, float(kc), 2 * kc, al, be, k=kc)
+        om = orc.Changepoint(x, y, kc, 1.0, 3.0, float(kc), al, be)
+        th0 = np.concatenate([np.sort(g.uniform(1.05, 2.95, size=(N, kc)), axis=1),
+                              g.uniform(1.0, 3.0, size=(N, kc + 1)), g.uniform(0.3, 1.0, size=(N, 1))], axis=1)
+        if N > 2:
+            th0[1, 0] = 3.5          # a chain outside the support
+    elif kind in ("gauss", "bigd"):
         mu, Ct = g.standard_normal(d), spd(g, d)
         m, om = MultiGaussianDist(mu, Ct), orc.Gaussian(mu, Ct)
         th0 = th0 + mu
@@ -45,8 +61,13 @@ def one(g, it):
         om = orc.Mixture(comps)
     Cp = (0.5 / d) * spd(g, d)
     props = ["rw", "arw", "pcn", "apcn", "acov", "pt"]
-    if kind != "mix":
+    if kind in ("gauss", "logreg"):
         props += ["hmc", "mala", "hmcm", "ahmc"]
+    if kind == "cp":
+        Cp = 0.002 * np.eye(d)
+        props += ["block"]
+    if kind == "bigd":
+        props = ["rw"]
     pk = str(g.choice(props))
     desc = "%s d=%d N=%d T=%d nb=%d nt=%d %s" % (kind, d, N, T, nb, nt, pk)
     seed = int(g.integers(0, 2 ** 31))
@@ -65,7 +86,13 @@ def one(g, it):
         assert np.array_equal(pt._host_codes, code[:, idx]), desc + " codes"
         np.testing.assert_allclose(pt._host_thetas, ht[:, idx], rtol=1e-8, atol=1e-11, err_msg=desc)
         return desc
-    if pk == "rw":
+    if pk == "block":
+        pc = [float(g.uniform(0, 1)), float(g.uniform(0, 1)), float(g.uniform(0, 1))]
+        p = P.ChangepointRegression1DProp(m, 2.0)
+        p.P_cumprop_cpx, p.P_cumprop_cpv, p.P_cumprop_sig = pc
+        p.scale = 0.3
+        op = orc.BlockRandomWalk(np.diag(np.diag(p.L) ** 2), [kc, kc + 1, 1], pc, scale=0.3)
+    elif pk == "rw":
         p, op = P.MetropolisRandomWalk(Cp), orc.RandomWalk(Cp)
     elif pk == "arw":
         p, op, ad = P.AdaptScaleRandomWalk(Cp), orc.set_adapt(orc.RandomWalk(Cp), 0.25), orc.new_adapt_state(N)
@@ -98,12 +125,26 @@ def one(g, it):
         return desc
     s = ra.Sampler(m, p, th0, seed=seed)
     s.run(T, nb, nt)
-    ht, hl, acc = orc.run(om, op, th, om.log_posterior(th), st, T, adapt=ad, aux=aux)
-    assert np.array_equal(s._chain_accept, acc), desc + " accept"
-    np.testing.assert_allclose(s._chain_thetas, ht[nb::nt], rtol=1e-8, atol=1e-11, err_msg=desc)
-    ref = hl[nb::nt]
-    fin = np.isfinite(ref)
-    np.testing.assert_allclose(s._chain_logpost[fin], ref[fin], rtol=1e-8, atol=1e-10, err_msg=desc)
+    lp0 = om.log_posterior(th)
+    ht, hl, acc = orc.run(om, op, th, lp0, st, T, adapt=ad, aux=aux)
+
+    def check(tag, ht, hl, acc, nb, nt):
+        assert np.array_equal(s._chain_accept, acc), desc + tag + " accept"
+        np.testing.assert_allclose(s._chain_thetas, ht[nb::nt], rtol=1e-8, atol=1e-11, err_msg=desc + tag)
+        ref = hl[nb::nt]
+        assert np.array_equal(np.isfinite(s._chain_logpost), np.isfinite(ref)), desc + tag + " finite"
+        fin = np.isfinite(ref)
+        np.testing.assert_allclose(s._chain_logpost[fin], ref[fin], rtol=1e-8, atol=1e-10, err_msg=desc + tag)
+    check("", ht, hl, acc, nb, nt)
+    kept = (T - nb) // nt + 1 if T >= nb else 0
+    if kept:    # a second run() continues from the LAST KEPT entry (sampler.py:49-50, 53-54)
+        last = nb + (kept - 1) * nt
+        th2, lp2 = np.ascontiguousarray(ht[last]).copy(), np.ascontiguousarray(hl[last]).copy()
+        T2, nb2, nt2 = int(g.integers(0, 8)), int(g.integers(0, 4)), int(g.integers(1, 3))
+        desc += " | T=%d nb=%d nt=%d" % (T2, nb2, nt2)
+        s.run(T2, nb2, nt2)
+        ht, hl, acc = orc.run(om, op, th2, lp2, st, T2, adapt=ad, aux=aux)
+        check(" second run", ht, hl, acc, nb2, nt2)
     return desc
 
 

@@ -1,0 +1,23 @@
+"""A fixed slice of the randomised differential test (tools/fuzz_vs_oracle.py): random
+model x proposal x size x run-schedule configurations on the device against the CPU oracle.
+The tool itself has been run over several thousand configurations."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_configurations_vs_oracle():
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_vs_oracle.py")
+    spec = importlib.util.spec_from_file_location("fuzz_vs_oracle", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    g = np.random.default_rng(2026)
+    seen = set()
+    for it in range(120):
+        desc = fz.one(g, it)
+        seen.add((desc.split()[0], desc.split("|")[0].split()[-1]))
+    assert {k for k, _ in seen} == {"gauss", "logreg", "mix", "cp", "bigd"}    # every model family came up

@@ -62,7 +62,9 @@ def one(g, it):
     Cp = (0.5 / d) * spd(g, d)
     props = ["rw", "arw", "pcn", "apcn", "acov", "pt"]
     if kind in ("gauss", "logreg"):
-        props += ["hmc", "mala", "hmcm", "ahmc"]
+        props += ["hmc", "mala", "hmcm", "ahmc", "acovhmc"]
+    if kind != "bigd":
+        props += ["asc"]
     if kind == "cp":
         Cp = 0.002 * np.eye(d)
         props += ["block"]
@@ -74,17 +76,26 @@ def one(g, it):
     ad = aux = None
     th, st = th0.copy(), orc.rng_seed(seed, N)
     if pk == "pt":
-        K = int(g.integers(1, 7))
-        betas = np.sort(g.uniform(0.05, 1.0, size=K))[::-1].copy()
-        pt = PTSampler(m, P.MetropolisRandomWalk(Cp), th0, betas=betas, Pswap=0.3, seed=seed)
-        pt.run(T)
+        K = int(g.choice([1, 2, 3, 4, 5, 7, 8, 15, 16, int(g.integers(1, 17))]))
+        betas = np.sort(g.uniform(0.0, 1.0, size=K))[::-1].copy()
+        pswap = float(g.uniform(0.05, 0.9))
+        chain0 = 16 * int(g.integers(0, 1000))
+        pt = PTSampler(m, P.MetropolisRandomWalk(Cp), th0, betas=betas, Pswap=pswap, seed=seed, chain0=chain0)
+        T1 = int(g.integers(0, T + 1))
+        pt.run(T1)                       # histories append across run() calls
+        pt.run(T - T1)
         S, idx = orc.pt_slots(N, K)
         slots = np.zeros((S, d))
         slots[:] = th0[0]
         slots[idx] = th0[:, None, :]
-        ht, hl, code, _ = orc.run_pt(om, orc.RandomWalk(Cp), slots, orc.rng_seed(seed, S), T, betas, 0.3)
+        ht, hl, code, _ = orc.run_pt(om, orc.RandomWalk(Cp), slots, orc.rng_seed(seed, S, chain0=chain0), T, betas, pswap)
+        desc += " K=%d T1=%d" % (K, T1)
         assert np.array_equal(pt._host_codes, code[:, idx]), desc + " codes"
         np.testing.assert_allclose(pt._host_thetas, ht[:, idx], rtol=1e-8, atol=1e-11, err_msg=desc)
+        ref = hl[:, idx]
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(pt._host_logpost), fin), desc + " finite"
+        np.testing.assert_allclose(pt._host_logpost[fin], ref[fin], rtol=1e-8, atol=1e-10, err_msg=desc)
         return desc
     if pk == "block":
         pc = [float(g.uniform(0, 1)), float(g.uniform(0, 1)), float(g.uniform(0, 1))]
@@ -111,15 +122,23 @@ def one(g, it):
         p, op = P.VanillaHMC(0.2, 3, m, M=Mm), orc.HMC(0.2, 3, d, M=Mm)
     elif pk == "ahmc":
         p, op, ad = P.AdaptScaleHMC(0.2, 2, m), orc.set_adapt(orc.HMC(0.2, 2, d), 0.75), orc.new_adapt_state(N)
-    elif pk == "acov":
+    elif pk in ("acov", "asc", "acovhmc"):
         if d > 111:
             return desc + " (skipped)"
-        p = P.AdaptCovRandomWalk(Cp, t_adapt=50, smooth_adapt=True)
+        sq = bool(g.integers(0, 2))
+        if pk == "acov":
+            p, op = P.AdaptCovRandomWalk(Cp, t_adapt=50, smooth_adapt=True, exact_squares=sq), orc.RandomWalk(Cp)
+        elif pk == "asc":
+            p = P.AdaptScaleCovRandomWalk(Cp, t_adapt=50, smooth_adapt=True, exact_squares=sq)
+            op, ad = orc.set_adapt(orc.RandomWalk(Cp), 0.25), orc.new_adapt_state(N)
+        else:
+            Cp = spd(g, d)
+            p, op = P.AdaptCovHMC(0.2, 2, m, Cp, t_adapt=50, smooth_adapt=True, exact_squares=sq), orc.HMC(0.2, 2, d, M=Cp)
         s = ra.Sampler(m, p, th0, seed=seed)
         s.run(T, nb, nt)
         stc = orc.new_adaptcov_state(Cp)
-        ht, hl, acc = orc.run_adaptcov(om, orc.RandomWalk(Cp), th, om.log_posterior(th), st, T, stc, Cp,
-                                       t_adapt=50, smooth_adapt=True)
+        ht, hl, acc = orc.run_adaptcov(om, op, th, om.log_posterior(th), st, T, stc, Cp,
+                                       t_adapt=50, smooth_adapt=True, exact_squares=sq, adapt=ad)
         assert np.array_equal(s._chain_accept, acc), desc + " accept"
         np.testing.assert_allclose(s._chain_thetas, ht[nb::nt], rtol=1e-7, atol=1e-10, err_msg=desc)
         return desc

@@ -59,6 +59,15 @@ def one(g, it):
         comps = [(float(g.uniform(0.2, 1)), g.standard_normal(d), spd(g, d)) for _ in range(int(g.integers(1, 4)))]
         m = MixtureDist([(w, MultiGaussianDist(mu, C)) for w, mu, C in comps])
         om = orc.Mixture(comps)
+    # the Model entry points on the starting states
+    for fn in ("log_prior", "log_likelihood", "log_posterior"):
+        a, b = np.atleast_1d(getattr(m, fn)(th0)), getattr(om, fn)(th0)
+        assert np.array_equal(np.isfinite(a), np.isfinite(b)), "%s %s d=%d finite" % (kind, fn, d)
+        fin = np.isfinite(b)
+        np.testing.assert_allclose(a[fin], b[fin], rtol=1e-8, atol=1e-10, err_msg="%s %s d=%d" % (kind, fn, d))
+    if kind in ("gauss", "logreg"):
+        np.testing.assert_allclose(m.grad_log_posterior(th0), om.grad_log_posterior(th0), rtol=1e-7, atol=1e-9,
+                                   err_msg="%s grad d=%d" % (kind, d))
     Cp = (0.5 / d) * spd(g, d)
     props = ["rw", "arw", "pcn", "apcn", "acov", "pt"]
     if kind in ("gauss", "logreg"):

@@ -212,15 +212,19 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs
     Xo rng = xo_load(ch.rng, ch.nslots, slot);
 
     int64_t knext = run.nburn, kentry = 0;
+    // raw buffer stores (descriptor per entry in SGPRs, row offset scalar, one VGPR lane
+    // offset): flat addressing spent a 64-bit multiply-add per stored row
+    const uint32_t hvoff = (uint32_t)((int64_t)g * ch.ld + c) * 8u, hrow = (uint32_t)ch.ld * 32u;
     auto rec = [&](int64_t e) {
         if (e != knext) return;
         knext += run.nthin;
         const int64_t k = kentry++;
         if (!run.h_theta) return;
-        double *dst = run.h_theta + k * (int64_t)(4 * ch.ks) * ch.ld;
+        const __amdgpu_buffer_rsrc_t r =
+            rsrc(run.h_theta + k * (int64_t)(4 * ch.ks) * ch.ld, (int64_t)(4 * ch.ks) * ch.ld);
 #pragma unroll
         for (int s = 0; s < S; ++s)
-            if (4 * s + g < D) dst[(int64_t)(4 * s + g) * ch.ld + c] = pick<D>(th, 4 * s, g);
+            if (4 * s + g < D) buf_store(r, hvoff, hrow * (uint32_t)s, pick<D>(th, 4 * s, g));
         if (g == 0) run.h_logpost[k * ch.ld + c] = lp;
     };
     rec(0);

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libriemann_hip.so")
-SOURCES = ["rmh_api.hip", "rmh_kernels_mfma.hip", "rmh_kernels_cp.hip", "rmh_kernels_big.hip",
+SOURCES = ["rmh_api.hip", "rmh_run_api.hip", "rmh_kernels_mfma.hip", "rmh_kernels_cp.hip", "rmh_kernels_big.hip",
            "rmh_comm.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
          "-Wall", "-Wno-unused-function"]

@@ -801,6 +801,11 @@ int rmh_state_create(rmh_model_t m, int64_t N, uint64_t seed, uint64_t chain0, r
 {
     RMH_NEED_INIT();
     if (!m || N < 1) return fail(RMH_ERR_PARAM, "state: need a model and N >= 1 chains");
+    // the kernels address a (rows, ld) array through 32-bit byte offsets (raw buffer instructions)
+    if ((int64_t)16 * m->NT * pad16(N) * 8 >= ((int64_t)1 << 32))
+        return fail(RMH_ERR_PARAM, "state: too many chains for one state at this dimension "
+                                   "(rows x chains x 8 bytes must stay below 4 GiB); split the chains "
+                                   "over several Samplers");
     rmh_state *s = new rmh_state;
     s->m = m;
     s->N = N;

@@ -1302,3 +1302,14 @@ def test_adaptive_covariance_run_of_zero_steps(ra):
     s.run(3)
     assert s._chain_thetas.shape == (4, 17, 15)
     np.testing.assert_array_equal(s._chain_thetas[0], th0)
+
+
+def test_chain_count_limit_is_reported(ra):
+    """32-bit buffer offsets bound rows x chains: beyond that the state is refused, not corrupted."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd import _lib
+    import ctypes as C
+    m = MultiGaussianDist(np.zeros(100), np.eye(100))        # 112 rows
+    h = C.c_void_p()
+    with pytest.raises(ra.ParameterError):
+        _lib.call("rmh_state_create", m._h, 5_000_000, 0, 0, C.byref(h))

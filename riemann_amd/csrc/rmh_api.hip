@@ -725,6 +725,11 @@ int rmh_proposal_free(rmh_proposal_t p)
     (void)hipFree(p->d_VT);
     (void)hipFree(p->d_acov_acc);
     (void)hipFree(p->d_acov_partial);
+    (void)hipFree(p->d_acov_C0);
+    (void)hipFree(p->d_acov_C);
+    (void)hipFree(p->d_acov_L);
+    (void)hipFree(p->d_acov_tmp);
+    (void)hipFree(p->d_acov_status);
     delete p;
     return RMH_OK;
 }

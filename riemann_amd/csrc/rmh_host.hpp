@@ -49,6 +49,12 @@ struct rmh_proposal {
     int acov_NT = 0;                            // tiles of the (d+1)-row moment matrix
     std::vector<double> acov_C0, acov_C;        // initial and current covariance (host)
     double *d_acov_acc = nullptr, *d_acov_partial = nullptr; // moment sums, per-workgroup partials
+    // device-side update (random-walk variant): C0, the current C and L, a scratch copy of the
+    // sums for the all-reduce, the not-positive-definite flag; the host copies acov_C / L are
+    // refreshed on demand (acov_host_stale)
+    double *d_acov_C0 = nullptr, *d_acov_C = nullptr, *d_acov_L = nullptr, *d_acov_tmp = nullptr;
+    int *d_acov_status = nullptr;
+    bool acov_host_stale = false;
 };
 
 struct rmh_state {

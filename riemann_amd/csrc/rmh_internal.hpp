@@ -158,6 +158,18 @@ hipError_t launch_cp_eval(int k, const CpArgs &m, const ChainArgs &c, double *lp
 hipError_t launch_cp_rw(int k, const CpArgs &m, const RwArgs &p, const ChainArgs &c,
                         const RunArgs &r, hipStream_t st);
 
+// device-side covariance update of the pooled AdaptCov (k_acov_update, rmh_kernels_mfma.hip)
+struct AcovUpdateArgs {
+    const double *acc;   // moment sums, tile-pair layout of k_moments, (d+1) x (d+1)
+    const double *C0;    // (d, d)
+    double *Cout, *Lout; // (d, d) adapted covariance (C / d^0.4) and factor (chol / d^0.2)
+    double *Limg;        // lower-triangular tile image of img_scale * L, NT tiles
+    int *status;
+    int d, NT;
+    double t_adapt, f4, f2, img_scale;
+    int marginalize, smooth;
+};
+hipError_t launch_acov_update(const AcovUpdateArgs &a, hipStream_t st);
 // pooled second moments of history entries [e0, e1): see rmh_kernels_mfma.hip
 hipError_t launch_moments(int NT, const double *hist, int64_t e0, int64_t e1, int rows, int64_t ld,
                           int64_t N, int d, double *partial, int nwg, double *acc, hipStream_t st);

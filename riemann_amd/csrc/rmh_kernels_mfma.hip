@@ -339,6 +339,88 @@ hipError_t launch_moments(int NT, const double *hist, int64_t e0, int64_t e1, in
     })
 }
 
+// ---- the covariance update of AdaptCovProposal.adapt (adaptive.py:83-102) on the device ----
+// One workgroup: C from the pooled moments (same expressions, same order as the host version
+// in rmh_run_api.hip), Cholesky in LDS (right-looking; every element receives its
+// subtractions in the same order as the host's left-looking loop, so the factor is bit
+// identical), L /= d^0.2, and the proposal's tile image scale * L written in place -- the
+// launch schedule of an adaptive run then needs no host round trip between updates.
+// status: set to 1 when a pivot is not positive (numpy raises LinAlgError at adaptive.py:102).
+
+RMH_DEV double mom_at(const double *acc, int row, int col)
+{
+    if (row < col) {
+        const int t = row;
+        row = col;
+        col = t;
+    }
+    const int i = row >> 4, j = col >> 4, t = i * (i + 1) / 2 + j;
+    const int rr = row & 15, l = (rr & 3) * 16 + (col & 15), r = rr >> 2;
+    return acc[(size_t)t * 256 + r * 64 + l];
+}
+
+__global__ void __launch_bounds__(256) k_acov_update(AcovUpdateArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double A[]; // d x d, row-major
+    const int d = a.d, tid = threadIdx.x;
+    const double ntot = mom_at(a.acc, d, d);
+    double tr = 0.0;
+    for (int i = 0; i < d; ++i) tr += a.C0[(size_t)i * d + i];
+    const double creg = 1e-12 * (tr / d);
+    for (int idx = tid; idx < d * d; idx += 256) {
+        const int i = idx / d, j = idx - i * d;
+        const double cs = (mom_at(a.acc, i, j) - mom_at(a.acc, i, d) * mom_at(a.acc, j, d) / ntot) / (ntot - 1);
+        double cv;
+        if (a.smooth) cv = (ntot * cs + a.t_adapt * a.C0[idx]) / (ntot + a.t_adapt);
+        else if (ntot < a.t_adapt) cv = a.C0[idx];
+        else cv = cs + (i == j ? creg : 0.0);
+        if (a.marginalize && i != j) cv = 0.0;
+        cv = cv / a.f4;
+        A[idx] = cv;
+        a.Cout[idx] = cv;
+    }
+    __syncthreads();
+    const int ti = tid >> 4, tk = tid & 15;
+    for (int j = 0; j < d; ++j) {
+        if (tid == 0) {
+            const double piv = A[j * d + j];
+            if (!(piv > 0.0)) *a.status = 1;
+            A[j * d + j] = sqrt(piv);
+        }
+        __syncthreads();
+        const double ljj = A[j * d + j];
+        for (int i = j + 1 + tid; i < d; i += 256) A[i * d + j] = A[i * d + j] / ljj;
+        __syncthreads();
+        for (int i = j + 1 + ti; i < d; i += 16) {
+            const double lij = A[i * d + j];
+            for (int k = j + 1 + tk; k <= i; k += 16) A[i * d + k] = A[i * d + k] - lij * A[k * d + j];
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < d * d; idx += 256) {
+        const int i = idx / d, j = idx - i * d;
+        a.Lout[idx] = (j <= i) ? A[idx] / a.f2 : 0.0;
+    }
+    // tile image: tile (i, s), s <= 4i+3, at index 2i(i+1)+s; lane l <- L[16i + (l&15)][4s + (l>>4)]
+    const int ntile = 2 * a.NT * (a.NT + 1);
+    for (int idx = tid; idx < ntile * 64; idx += 256) {
+        const int tl = idx >> 6, l = idx & 63;
+        int i = 0;
+        while (2 * (i + 1) * (i + 2) <= tl) ++i;
+        const int sidx = tl - 2 * i * (i + 1);
+        const int row = 16 * i + (l & 15), col = 4 * sidx + (l >> 4);
+        double v = 0.0;
+        if (row < d && col < d && col <= row) v = A[row * d + col] / a.f2;
+        a.Limg[idx] = a.img_scale * v;
+    }
+}
+
+hipError_t launch_acov_update(const AcovUpdateArgs &a, hipStream_t st)
+{
+    const size_t lds = sizeof(double) * (size_t)a.d * a.d;
+    return launch(k_acov_update, 4, 4, lds, st, a); // one workgroup of 256 threads
+}
+
 // ------------------------------------------------------------------ utilities
 __global__ void k_rng_seed(uint64_t *rng, int64_t nslots, uint64_t seed, uint64_t chain0)
 {

@@ -13,6 +13,7 @@ int comm_allreduce_sum(double *dev, size_t count);
 } // namespace rmh
 
 // ---- AdaptCovProposal, pooled over the chains (proposals/adaptive.py:38-103) -------------
+constexpr int kAcovDeviceMaxDim = 48; // covariance updates on the device up to this dimension
 constexpr int kAcovChunk = 64;   // iterations per launch at most (scratch history size)
 constexpr int kAcovWGs = 512;    // workgroups of the moment kernel: two per CU (59 KB of LDS each)
 
@@ -89,8 +90,61 @@ bool cholesky_lower(const std::vector<double> &Cm, int d, std::vector<double> &L
 
 // the covariance update of adaptive.py:83-102 from the pooled moments (local sums are
 // all-reduced over the ranks first when a communicator exists)
+// refresh the host copies of C and L after device-side updates
+static int acov_sync_host(rmh_proposal *p)
+{
+    if (!p->acov_host_stale) return RMH_OK;
+    const size_t n = (size_t)p->d * p->d;
+    int st = 0;
+    p->acov_C.resize(n);
+    p->L.resize(n);
+    RMH_HIP(hipMemcpyAsync(p->acov_C.data(), p->d_acov_C, n * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    RMH_HIP(hipMemcpyAsync(p->L.data(), p->d_acov_L, n * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    RMH_HIP(hipMemcpyAsync(&st, p->d_acov_status, sizeof(int), hipMemcpyDeviceToHost, g_stream));
+    RMH_HIP(hipStreamSynchronize(g_stream));
+    p->acov_host_stale = false;
+    if (st) // numpy raises LinAlgError at adaptive.py:102
+        return fail(RMH_ERR_HIP, "AdaptCov: the adapted covariance is not positive definite");
+    return RMH_OK;
+}
+
+// random-walk variant: the whole update stays on the device (no host round trip)
+static int acov_update_device(rmh_proposal *p)
+{
+    const int d = p->d, n = acov_ntri(p) * 256;
+    const double *acc = p->d_acov_acc;
+    if (rmh::comm_active()) { // pooled over the ranks: all-reduce a copy of this rank's sums
+        RMH_HIP(hipMemcpyAsync(p->d_acov_tmp, p->d_acov_acc, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
+        int rc = rmh::comm_allreduce_sum(p->d_acov_tmp, (size_t)n);
+        if (rc) return rc;
+        acc = p->d_acov_tmp;
+    }
+    AcovUpdateArgs a{};
+    a.acc = acc;
+    a.C0 = p->d_acov_C0;
+    a.Cout = p->d_acov_C;
+    a.Lout = p->d_acov_L;
+    a.Limg = p->d_Ltiles;
+    a.status = p->d_acov_status;
+    a.d = d;
+    a.NT = p->NT;
+    a.t_adapt = p->acov_t_adapt;
+    a.f4 = std::pow((double)d, 0.4);
+    a.f2 = std::pow((double)d, 0.2);
+    a.img_scale = p->adapt_target > 0 ? 1.0 : p->scale;   // as sync_proposal packs it
+    a.marginalize = p->acov_marg;
+    a.smooth = p->acov_smooth;
+    RMH_HIP(launch_acov_update(a, g_stream));
+    p->acov_host_stale = true;
+    return RMH_OK;
+}
+
 static int acov_update(rmh_proposal *p)
 {
+    // Measured (tools/adaptcov_timing.py, examples): the one-workgroup device update beats the
+    // host round trip for small matrices (d = 2: 348 -> 181 ms for 10 000 steps of 4096 chains)
+    // and loses to it at d = 100 (175 -> 212 ms: ~300 barriers of a right-looking Cholesky)
+    if (p->kind == kRW && p->d <= kAcovDeviceMaxDim) return acov_update_device(p);
     const int d = p->d, D1 = d + 1, n = acov_ntri(p) * 256;
     std::vector<double> acc((size_t)n), Mm;
     if (rmh::comm_active()) {
@@ -212,6 +266,12 @@ static int run_adaptcov(rmh_model *m, rmh_proposal *p, rmh_state *s, const Chain
         done += seg;
         if (acov_due(p, p->acov_n) && (rc = acov_update(p))) return rc;
     }
+    if (p->acov_host_stale) { // one look at the not-positive-definite flag per run
+        int st = 0;
+        RMH_HIP(hipMemcpyAsync(&st, p->d_acov_status, sizeof(int), hipMemcpyDeviceToHost, g_stream));
+        RMH_HIP(hipStreamSynchronize(g_stream));
+        if (st) return fail(RMH_ERR_HIP, "AdaptCov: the adapted covariance is not positive definite");
+    }
     return RMH_OK;
 }
 
@@ -234,8 +294,10 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         if (m->kind == kChangepoint)
             return fail(RMH_ERR_PARAM, "hmc: the changepoint model has no gradient");
         if ((rc = ensure_grad(s))) return rc;
-    } else if ((rc = sync_proposal(p))) {
-        return rc;
+    } else {
+        // a re-pack of the tile image (changed .scale) reads the host copy of L
+        if (p->acov && p->dirty && (rc = acov_sync_host(p))) return rc;
+        if ((rc = sync_proposal(p))) return rc;
     }
     const bool adapt = p->adapt_target > 0;
     if (adapt && (rc = ensure_adapt(s))) return rc;
@@ -396,6 +458,16 @@ int rmh_proposal_set_adapt_cov(rmh_proposal_t p, const double *C0, double t_adap
     int rc = dev_alloc(&p->d_acov_acc, n);
     if (rc) return rc;
     RMH_HIP(hipMemset(p->d_acov_acc, 0, n * sizeof(double)));
+    (void)hipFree(p->d_acov_C0); (void)hipFree(p->d_acov_C); (void)hipFree(p->d_acov_L);
+    (void)hipFree(p->d_acov_tmp); (void)hipFree(p->d_acov_status);
+    p->d_acov_C0 = p->d_acov_C = p->d_acov_L = p->d_acov_tmp = nullptr;
+    p->d_acov_status = nullptr;
+    p->acov_host_stale = false;
+    if ((rc = upload(&p->d_acov_C0, C.data(), C.size())) || (rc = upload(&p->d_acov_C, C.data(), C.size())) ||
+        (rc = upload(&p->d_acov_L, L.data(), L.size())) || (rc = dev_alloc(&p->d_acov_tmp, n)) ||
+        (rc = dev_alloc(&p->d_acov_status, (size_t)1)))
+        return rc;
+    RMH_HIP(hipMemset(p->d_acov_status, 0, sizeof(int)));
     return RMH_OK;
 }
 
@@ -404,6 +476,8 @@ int rmh_proposal_adapt_cov_get(rmh_proposal_t p, double *st)
 {
     if (!p || !p->acov || !st) return fail(RMH_ERR_PARAM, "adapt_cov_get: not an AdaptCov proposal");
     const int d = p->d, D1 = d + 1;
+    int rcs = acov_sync_host(p);
+    if (rcs) return rcs;
     std::vector<double> acc((size_t)acov_ntri(p) * 256), Mm;
     RMH_HIP(hipMemcpy(acc.data(), p->d_acov_acc, acc.size() * sizeof(double), hipMemcpyDeviceToHost));
     acov_unpack(p, acc, Mm);
@@ -437,6 +511,9 @@ int rmh_proposal_adapt_cov_set(rmh_proposal_t p, const double *st, double count)
     p->acov_C.assign(C, C + (size_t)d * d);
     p->L.assign(L, L + (size_t)d * d);
     p->dirty = true;
+    p->acov_host_stale = false;
+    RMH_HIP(hipMemcpy(p->d_acov_C, C, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice));
+    RMH_HIP(hipMemcpy(p->d_acov_L, L, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice));
     if (p->kind == kHMC) {
         p->minv = L[(size_t)d * d] != 0.0 ? L[(size_t)d * d] : 1.0;
         return install_mass(p, p->L.data());

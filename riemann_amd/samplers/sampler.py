@@ -141,6 +141,59 @@ class Sampler(object):
             self._host_logpost = np.empty((0, self.Nchains))
             self._host_accept = np.empty((0, self.Nchains), dtype=np.uint8)
 
+    def run_to_disk(self, prefix, Nsamples, Nburn=0, Nthin=1, chunk=1000):
+        """``run(Nsamples, Nburn, Nthin)`` with the kept states streamed to disk instead of
+        held in memory: ``prefix + "_thetas.npy"`` (n, N, d),
+        ``"_logpost.npy"`` (n, N) and ``"_accept.npy"`` (Nsamples, N) are standard .npy files,
+        written chunk by chunk through memory maps (``numpy.load(..., mmap_mode="r")`` reads
+        them back lazily).  The iterations are launched ``chunk`` at a time; the chains and
+        their random streams are the same as for one ``run`` call.  Returns the number of kept
+        states.  The in-memory history afterwards holds only the last kept state."""
+        T, nb, nt, chunk = int(Nsamples), int(Nburn), int(Nthin), int(chunk)
+        if T < 0 or nb < 0 or nt < 1 or chunk < 1:
+            raise _lib.ParameterError("need Nsamples >= 0, Nburn >= 0, Nthin >= 1, chunk >= 1")
+        kept = (T - nb) // nt + 1 if T >= nb else 0
+        N, d = self.Nchains, self.Npars
+        shp = (kept, d) if self._single else (kept, N, d)
+        fth = np.lib.format.open_memmap(prefix + "_thetas.npy", mode="w+", dtype=np.float64, shape=shp)
+        flp = np.lib.format.open_memmap(prefix + "_logpost.npy", mode="w+", dtype=np.float64, shape=shp[:-1])
+        fac = np.lib.format.open_memmap(prefix + "_accept.npy", mode="w+", dtype=np.uint8,
+                                        shape=(T,) if self._single else (T, N))
+        done, out = 0, 0
+        while True:
+            step = min(chunk, T - done)
+            # global state numbers done .. done+step; kept iff e >= nb and (e - nb) % nt == 0.
+            # Within the chunk the local state 0 is the global state `done` (kept by the previous
+            # chunk unless this is the first one).
+            first = nb if done == 0 and nb <= 0 else max(nb, done + (1 if done else 0))
+            first += (-(first - nb)) % nt                     # next kept global state number
+            self.run(step, 0, 1)                              # every state of the chunk, then slice
+            th, lp, ac = self._chain_thetas, self._chain_logpost, self._chain_accept
+            loc = np.arange(first - done, step + 1, nt) if first - done <= step else np.arange(0)
+            n = len(loc)
+            if n:
+                fth[out:out + n], flp[out:out + n] = th[loc], lp[loc]
+                out += n
+            fac[done:done + step] = ac
+            done += step
+            if done >= T:
+                break
+        for f in (fth, flp, fac):
+            f.flush()
+        assert out == kept, (out, kept)
+        # as after run(): the current state is the LAST KEPT one (sampler.py:49-50, 53-54)
+        if kept == 0:
+            self.run(0, 1, 1)                                   # keeps nothing: no current state
+        elif nb + (kept - 1) * nt != T:
+            last = np.asarray(fth[kept - 1])
+            _lib.call("rmh_state_set_theta", self._state, _lib.as_f64(np.atleast_2d(last)))
+            self._host_thetas = np.atleast_2d(last)[None].copy()
+            self._host_logpost = np.atleast_1d(np.asarray(flp[kept - 1]))[None].copy()
+            self._host_accept = np.zeros((0, self.Nchains), dtype=np.uint8)
+            self._drop_history()
+            self._kept = 1
+        return kept
+
     # ------------------------------------------------------ checkpoint / resume --
     def checkpoint(self, path):
         """Write the chains' resumable state to ``path`` (.npz): current states,

@@ -1313,3 +1313,30 @@ def test_chain_count_limit_is_reported(ra):
     h = C.c_void_p()
     with pytest.raises(ra.ParameterError):
         _lib.call("rmh_state_create", m._h, 5_000_000, 0, 0, C.byref(h))
+
+
+def test_run_to_disk_streams_the_same_samples(ra, tmp_path):
+    """Thinned samples streamed to .npy files chunk by chunk == one in-memory run()."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    g = np.random.default_rng(0)
+    th0 = g.standard_normal((37, 5))
+    m = MultiGaussianDist(np.zeros(5), np.eye(5))
+    for T, nb, nt, chunk in ((50, 0, 1, 16), (53, 7, 4, 10), (20, 25, 2, 8), (31, 31, 3, 31), (0, 0, 1, 5)):
+        a = ra.Sampler(m, MetropolisRandomWalk(0.3 * np.eye(5)), th0, seed=4)
+        a.run(T, nb, nt)
+        b = ra.Sampler(m, MetropolisRandomWalk(0.3 * np.eye(5)), th0, seed=4)
+        kept = b.run_to_disk(str(tmp_path / "s"), T, nb, nt, chunk=chunk)
+        th = np.load(str(tmp_path / "s_thetas.npy"), mmap_mode="r")
+        assert kept == a._chain_thetas.shape[0] == th.shape[0]
+        np.testing.assert_array_equal(th, a._chain_thetas)
+        np.testing.assert_array_equal(np.load(str(tmp_path / "s_logpost.npy")), a._chain_logpost)
+        np.testing.assert_array_equal(np.load(str(tmp_path / "s_accept.npy")), a._chain_accept)
+        if kept:                                    # and the chains continue from the same state
+            np.testing.assert_array_equal(b.current_state()[0], a.current_state()[0])
+            a.run(3)
+            b.run(3)
+            np.testing.assert_array_equal(b._chain_thetas, a._chain_thetas)
+        else:
+            with pytest.raises(IndexError):
+                b.current_state()

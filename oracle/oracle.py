@@ -83,6 +83,9 @@ def lib():
     L.orc_run_adaptcov.restype = i32
     L.orc_run_adaptcov.argtypes = [vp, vp, i64, _f64p, _f64p, _u64p, i32, _f64p, _f64p, dbl, i32, i32,
                                    i32, vp, vp, vp, vp]
+    L.orc_cprj_log_posterior.argtypes = [vp, i32, _f64p, i64, _f64p]
+    L.orc_run_cprj.restype = i32
+    L.orc_run_cprj.argtypes = [vp, i32, dbl, _f64p, i64, _f64p, _f64p, _u64p, i32, vp, vp, vp, vp]
     L.orc_max_threads.restype = i32
     _lib = L
     return L
@@ -379,6 +382,41 @@ def run_pt(model, proposal, theta, rng_state, T, betas, pswap, history=True):
     if rc != 0:
         raise ValueError("oracle: bad parallel-tempering arguments")
     return ht, hl, code, logpost
+
+
+def cprj_pack(params, KM):
+    """[(cpx, cpv, sig), ...] -> padded (N, 2 KM + 3) states of the trans-dimensional
+    changepoint sampler (rmh_oracle.c section 6)."""
+    out = np.zeros((len(params), 2 * KM + 3))
+    out[:, :KM] = np.inf
+    out[:, KM:2 * KM + 1] = 1.0
+    for r, (cpx, cpv, sig) in zip(out, params):
+        k = len(cpx)
+        r[:k], r[KM:KM + k + 1], r[2 * KM + 1], r[2 * KM + 2] = cpx, cpv, sig, k
+    return out
+
+
+def cprj_unpack(row, KM):
+    k = int(row[2 * KM + 2])
+    return row[:k].copy(), row[KM:KM + k + 1].copy(), float(row[2 * KM + 1])
+
+
+def cprj_log_posterior(model, KM, theta):
+    th = _c(np.atleast_2d(theta))
+    out = np.empty(th.shape[0])
+    lib().orc_cprj_log_posterior(model._h, KM, th, th.shape[0], out)
+    return out
+
+
+def run_cprj(model, KM, hscale, pcum, theta, logpost, rng_state, T):
+    """Trans-dimensional changepoint sampling over N chains (rmh_oracle.c section 6).
+    Returns (hist_theta (T+1,N,2KM+3), hist_logpost (T+1,N), accept (T,N), move (T,N))."""
+    N, D = theta.shape
+    ht, hl = np.empty((T + 1, N, D)), np.empty((T + 1, N))
+    acc, mv = np.empty((T, N), dtype=np.uint8), np.empty((T, N), dtype=np.uint8)
+    lib().orc_run_cprj(model._h, KM, float(hscale), _c(pcum), N, theta, logpost, rng_state, T,
+                       ht.ctypes.data, hl.ctypes.data, acc.ctypes.data, mv.ctypes.data)
+    return ht, hl, acc, mv
 
 
 def max_threads():

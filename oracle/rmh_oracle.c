@@ -1049,6 +1049,140 @@ int orc_run_pt(const orc_model *m, const orc_proposal *p, int64_t S, double *the
     return 0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* 6. Trans-dimensional changepoint sampling                    */
+/* ------------------------------------------------------------------------- */
+/*
+ * The reference's changepoint script samples over the NUMBER of changepoints:
+ * ChangepointRegression1DProp.propose (riemann/test_changepoint.py:43-73) picks a block
+ * random walk (cpx / cpv / sig, :47-55) or else a birth / death move (:56-71) built on
+ * ChangepointRegression1D.add_changepoint / subtract_changepoint
+ * (riemann/models/changepoint.py:193-240) with the height map of :48-69; the model's
+ * log_prior / log_likelihood (:106-160) take any number of changepoints.
+ *
+ * State of one chain: a PADDED vector of 2 KM + 3 doubles,
+ *   [cpx (KM, +inf beyond k), cpv (KM+1, 1.0 beyond k+1), sig, k],
+ * KM = capacity (the model's kmax).  A birth at k = KM cannot be represented and is
+ * rejected (the reference's prior does not bound k; with Poisson(lamb) pieces such states
+ * have negligible mass).
+ *
+ * Stream per iteration (rmh-rng v2 extension): the normals of the 2 KM + 2 padded
+ * coordinates (a block of k entries uses the first k normals of its padded block), then
+ * TWO more words from every sub-stream:
+ *   first : sub-stream 0 accept uniform, 1..3 the chained block selectors U1, U2, U3
+ *   second: sub-stream 0 U4 (birth if k = 0 or U4 > 0.5, :58), 1 the new location
+ *           s = xmin + (xmax - xmin) U (:59), 2 the height split u = 0.5 + (-0.1 + 0.2 U) /
+ *           sqrt(n) (:60), 3 the changepoint to remove, floor(U k) (:66).
+ * Block covariances (:36-41): C_cpx = 0.01 (xmax-xmin)/(k+1), C_cpv = 0.01 hscale^2 / n,
+ * C_sig = 0.01 hscale, each times the identity; the proposal is theta + sqrt(C) xi.
+ * logqratio of a birth / death = log |det J| of the height map, which the reference gets
+ * from autograd; analytically log(h / (u (1-u))) for (h, u) -> (h1, h2) and its negative
+ * for the inverse.
+ * move (T,N) uint8: 0 cpx, 1 cpv, 2 sig, 3 birth, 4 death, 5 birth refused at capacity.
+ */
+static double orc_cprj_post(const orc_model *m, int KM, const double *pad, double *scratch)
+{
+    const int k = (int)pad[2 * KM + 2];
+    orc_model mm = *m;
+    mm.kind = ORC_CHANGEPOINT;
+    mm.k = k;
+    mm.d = 2 * k + 2;
+    double *c = scratch; /* compact [cpx k, cpv k+1, sig] */
+    for (int j = 0; j < k; j++) c[j] = pad[j];
+    for (int j = 0; j <= k; j++) c[k + j] = pad[KM + j];
+    c[2 * k + 1] = pad[2 * KM + 1];
+    return orc_log_post1(&mm, c, scratch + 2 * KM + 4);
+}
+
+void orc_cprj_log_posterior(const orc_model *m, int KM, const double *theta, int64_t N, double *out)
+{
+    double *scratch = (double *)malloc(sizeof(double) * (4 * KM + 16));
+    for (int64_t c = 0; c < N; c++) out[c] = orc_cprj_post(m, KM, theta + c * (2 * KM + 3), scratch);
+    free(scratch);
+}
+
+int orc_run_cprj(const orc_model *m, int KM, double hscale, const double *pcum, int64_t N,
+                 double *theta, double *logpost, u64 *rng, int T, double *hist_theta,
+                 double *hist_logpost, uint8_t *accept, uint8_t *move)
+{
+    const int D = 2 * KM + 3, Dn = 2 * KM + 2, n = (int)m->n;
+    double *xi = (double *)malloc(sizeof(double) * (Dn + 4)), *thp = (double *)malloc(sizeof(double) * D);
+    double *scratch = (double *)malloc(sizeof(double) * (4 * KM + 16));
+    const double sv = sqrt(0.01 * hscale * hscale / n), ss = sqrt(0.01 * hscale);
+    for (int64_t c = 0; c < N; c++) {
+        if (hist_theta) memcpy(hist_theta + c * D, theta + c * D, sizeof(double) * D);
+        if (hist_logpost) hist_logpost[c] = logpost[c];
+    }
+    for (int t = 0; t < T; t++)
+        for (int64_t c = 0; c < N; c++) {
+            double *th = theta + c * D;
+            u64 *st = rng + 16 * c;
+            orc_rng_normals(st, Dn, xi);
+            double w1[4], w2[4];
+            orc_rng_words(st, w1);
+            orc_rng_words(st, w2);
+            const int k = (int)th[2 * KM + 2];
+            memcpy(thp, th, sizeof(double) * D);
+            double logq = 0.0;
+            int mv;
+            if (w1[1] < pcum[0]) { /* :47-49 */
+                mv = 0;
+                const double sx = sqrt(0.01 * (m->xmax - m->xmin) / (k + 1));
+                for (int j = 0; j < k; j++) thp[j] = th[j] + sx * xi[j];
+            } else if (w1[2] < pcum[1]) { /* :50-52 */
+                mv = 1;
+                for (int j = 0; j <= k; j++) thp[KM + j] = th[KM + j] + sv * xi[KM + j];
+            } else if (w1[3] < pcum[2]) { /* :53-55 */
+                mv = 2;
+                thp[2 * KM + 1] = th[2 * KM + 1] + ss * xi[2 * KM + 1];
+            } else if (k == 0 || w2[0] > 0.5) { /* birth, :58-63 and changepoint.py:193-218 */
+                mv = 3;
+                const double s = m->xmin + (m->xmax - m->xmin) * w2[1];
+                const double u = 0.5 + (-0.1 + 0.2 * w2[2]) / sqrt((double)n);
+                if (k == KM) mv = 5;
+                else {
+                    int nn = 0;
+                    while (nn < k && th[nn] < s) nn++; /* searchsorted(cpx, s) */
+                    const double h = th[KM + nn], ufac = sqrt((1 - u) / u);
+                    for (int j = k; j > nn; j--) thp[j] = th[j - 1];
+                    thp[nn] = s;
+                    for (int j = k + 1; j > nn + 1; j--) thp[KM + j] = th[KM + j - 1];
+                    thp[KM + nn] = h / ufac;
+                    thp[KM + nn + 1] = h * ufac;
+                    thp[2 * KM + 2] = k + 1;
+                    logq = log(fabs(h / (u * (1 - u))));
+                }
+            } else { /* death, :65-71 and changepoint.py:220-240 */
+                mv = 4;
+                int nn = (int)(w2[3] * k);
+                if (nn >= k) nn = k - 1;
+                const double h1 = th[KM + nn], h2 = th[KM + nn + 1];
+                const double h = sqrt(h1 * h2), u = 1.0 / (1 + h2 / h1);
+                for (int j = nn; j < k - 1; j++) thp[j] = th[j + 1];
+                thp[k - 1] = INFINITY;
+                thp[KM + nn] = h;
+                for (int j = nn + 1; j < k; j++) thp[KM + j] = th[KM + j + 1];
+                thp[KM + k] = 1.0;
+                thp[2 * KM + 2] = k - 1;
+                logq = log(fabs(u * (1 - u) / h));
+            }
+            const double lpp = (mv == 5) ? -INFINITY : orc_cprj_post(m, KM, thp, scratch);
+            const double delta = lpp - logpost[c] - logq;
+            const double mh = (delta < 0) ? delta : 0.0;
+            const int acc = orc_log(w1[0]) < mh;
+            if (acc) {
+                memcpy(th, thp, sizeof(double) * D);
+                logpost[c] = lpp;
+            }
+            if (accept) accept[(int64_t)t * N + c] = (uint8_t)acc;
+            if (move) move[(int64_t)t * N + c] = (uint8_t)mv;
+            if (hist_theta) memcpy(hist_theta + ((int64_t)(t + 1) * N + c) * D, th, sizeof(double) * D);
+            if (hist_logpost) hist_logpost[(int64_t)(t + 1) * N + c] = logpost[c];
+        }
+    free(xi); free(thp); free(scratch);
+    return 0;
+}
+
 int orc_max_threads(void)
 {
 #ifdef _OPENMP

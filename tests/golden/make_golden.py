@@ -548,6 +548,129 @@ def g12_pt():
     save("g12_pt_mix2d", Cprop=1.5 * np.eye(2), **r)
 
 
+class RJReplay:
+    """Feeds one chain's draws to the reference's ChangepointRegression1DProp WITH its
+    trans-dimensional branch (riemann/test_changepoint.py:43-73): inside ``propose`` the
+    argument-less uniforms are U1, U2, U3 (block selectors) and U4 (birth/death, :58), the
+    two uniforms with bounds are the new location (:59) and the height split (:60), randint
+    is the changepoint to remove (:66); the block's normals are the first k (k+1) of its
+    padded block; Sampler.sample's uniform is the accept draw and closes the iteration."""
+
+    def __init__(self, xi, w1, w2, KM):
+        self.xi, self.w1, self.w2, self.KM = xi, w1, w2, KM      # (T,Dn), (T,4), (T,4)
+        self.t, self.nsel, self.nbnd = 0, 0, 0
+        self.move = np.full(len(w1), -1, dtype=np.int8)
+
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        shape = (size,) if np.isscalar(size) else tuple(size)
+        b, KM = self.nsel - 1, self.KM
+        lo = {0: 0, 1: KM, 2: 2 * KM + 1}[b]
+        self.move[self.t] = b
+        return self.xi[self.t, lo:lo + shape[0]].copy()
+
+    def uniform(self, low=None, high=None, size=None):
+        assert size is None
+        fr = sys._getframe(1)
+        if fr.f_code.co_name == "propose":
+            if low is None:
+                self.nsel += 1
+                return float(self.w1[self.t, self.nsel]) if self.nsel <= 3 else float(self.w2[self.t, 0])
+            self.nbnd += 1
+            self.move[self.t] = 3
+            return low + (high - low) * float(self.w2[self.t, self.nbnd])
+        assert fr.f_code.co_filename.endswith("sampler.py"), fr.f_code.co_filename
+        v = float(self.w1[self.t, 0])
+        self.t += 1
+        self.nsel = self.nbnd = 0
+        return v
+
+    def randint(self, n):
+        self.move[self.t] = 4
+        return min(int(float(self.w2[self.t, 3]) * n), n - 1)
+
+
+def g17_changepoint_rj():
+    """The reference's trans-dimensional changepoint sampler: ChangepointRegression1DProp
+    (riemann/test_changepoint.py:18-73) with its birth/death branch, on
+    ChangepointRegression1D.add_changepoint / subtract_changepoint
+    (models/changepoint.py:193-240).  P_cumprop_sig = 0 keeps the sig block out (it raises
+    under numpy >= 1.24, see g13): cpx 0.2, cpv 0.32, birth/death 0.48.  The autograd
+    stand-in differentiates the height map by the complex-step method (exact to rounding,
+    like the automatic differentiation it replaces)."""
+    import contextlib
+    import importlib.util
+    import io
+    cp = import_changepoint()
+
+    def jacobian(f):
+        def jac(p):
+            p = np.asarray(p, dtype=np.float64)
+            cols = []
+            for j in range(len(p)):
+                z = p.astype(np.complex128)
+                z[j] += 1e-30j
+                cols.append(np.imag(f(z)) / 1e-30)
+            return np.array(cols).T
+        return jac
+    cp.jacobian = jacobian
+    import riemann.models as rmodels
+    import riemann.proposals as rprops
+    rmodels.ChangepointParams, rmodels.ChangepointRegression1D = cp.ChangepointParams, cp.ChangepointRegression1D
+    rprops.MetropolisRandomWalk = MetropolisRandomWalk
+    spec = importlib.util.spec_from_file_location("riemann_ref_test_changepoint_rj",
+                                                  "/root/reference/riemann/test_changepoint.py")
+    tc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tc)
+    k0, KM = 5, 10
+    model, x, y, truth, Cdiag = changepoint_setup(cp)
+    hscale = 2.0
+    Dn = 2 * KM + 2
+    g = np.random.default_rng(17)
+    N, T = 4, 300
+    starts = []
+    for c in range(N):
+        kc = [5, 1, 0, 8][c]
+        cpx = np.sort(g.uniform(1.1, 2.9, size=kc))
+        starts.append((cpx, g.uniform(1.0, 3.0, size=kc + 1), 0.5))
+    th0 = orc.cprj_pack(starts, KM)
+    st = orc.rng_seed(170, N)
+    xi = np.empty((T, N, Dn)); w1 = np.empty((T, N, 4)); w2 = np.empty((T, N, 4))
+    for t in range(T):
+        for c in range(N):
+            s1 = st[c:c + 1]
+            xi[t, c] = orc.rng_normals(s1, Dn)
+            w1[t, c] = orc.rng_words(s1)
+            w2[t, c] = orc.rng_words(s1)
+    thetas = np.zeros((T + 1, N, 2 * KM + 3)); logpost = np.zeros((T + 1, N))
+    accept = np.zeros((T, N), dtype=np.uint8); move = np.zeros((T, N), dtype=np.int8)
+    real = np.random.normal, np.random.uniform, np.random.randint
+    try:
+        for c in range(N):
+            rp = RJReplay(xi[:, c], w1[:, c], w2[:, c], KM)
+            np.random.normal, np.random.uniform, np.random.randint = rp.normal, rp.uniform, rp.randint
+            prop = tc.ChangepointRegression1DProp(model, hscale)
+            prop.P_cumprop_sig = 0.0
+            t0 = cp.ChangepointParams(*starts[c])
+            s = Sampler(model, prop, t0)
+            with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+                s.run(T)
+            assert rp.t == T
+            for e, (tt, lp) in enumerate(zip(s._chain_thetas, s._chain_logpost)):
+                thetas[e, c] = orc.cprj_pack([(np.ravel(tt.cpx), np.ravel(tt.cpv), float(tt.sig))], KM)[0]
+                logpost[e, c] = lp
+            accept[:, c] = [s._chain_thetas[t + 1] is not s._chain_thetas[t] for t in range(T)]
+            move[:, c] = rp.move
+    finally:
+        np.random.normal, np.random.uniform, np.random.randint = real
+    ks = thetas[:, :, -1]
+    assert ks.max() <= KM and set(np.unique(move)) == {0, 1, 3, 4}
+    assert (accept[move == 3] == 1).sum() > 3 and (accept[move == 4] == 1).sum() > 3, "no accepted births/deaths"
+    save("g17_changepoint_rj", x=x, y=y, KM=np.int64(KM), xmin=np.float64(1.0), xmax=np.float64(3.0),
+         lamb=np.float64(k0), alpha=np.float64(1.0), beta=np.float64(1.0), hscale=np.float64(hscale),
+         pcum=np.array([0.2, 0.4, 0.0]), seed=np.uint64(170), theta0=th0, thetas=thetas, logpost=logpost,
+         accept=accept, move=move)
+
+
 def g14_adapt_cov():
     """AdaptCovRandomWalk (Haario et al. 2001), proposals/adaptive.py:38-103 with
     randomwalk.py:41-56: strict, smooth_adapt and marginalize variants, one chain each
@@ -787,3 +910,4 @@ if __name__ == "__main__":
     g14_adapt_cov()
     g15_gauss_big_d()
     g16_reference_example()
+    g17_changepoint_rj()

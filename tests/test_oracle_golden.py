@@ -485,3 +485,28 @@ def test_g16_the_reference_example_run():
     np.testing.assert_allclose(hl[1000:], z["logpost"], rtol=1e-7, atol=1e-10)
     assert ad[0, 1] == z["Naccepts"][0]
     np.testing.assert_allclose(ad[0, 2], z["scale_final"][0], rtol=1e-10)
+
+
+def test_g17_trans_dimensional_changepoint_sampler():
+    """The reference's ChangepointRegression1DProp with its birth/death branch
+    (riemann/test_changepoint.py:43-73, models/changepoint.py:193-240)."""
+    z = load("g17_changepoint_rj")
+    KM = int(z["KM"])
+    model = orc.Changepoint(z["x"], z["y"], 1, float(z["xmin"]), float(z["xmax"]), float(z["lamb"]),
+                            float(z["alpha"]), float(z["beta"]))
+    th = np.ascontiguousarray(z["theta0"]).copy()
+    N = th.shape[0]
+    lp = orc.cprj_log_posterior(model, KM, th)
+    np.testing.assert_allclose(lp, z["logpost"][0], rtol=RTOL)
+    st = orc.rng_seed(int(z["seed"]), N)
+    T = z["accept"].shape[0]
+    ht, hl, acc, mv = orc.run_cprj(model, KM, float(z["hscale"]), z["pcum"], th, lp, st, T)
+    np.testing.assert_array_equal(mv, z["move"])
+    np.testing.assert_array_equal(acc, z["accept"])
+    np.testing.assert_array_equal(ht[:, :, -1], z["thetas"][:, :, -1])          # k, exactly
+    fin = np.isfinite(z["thetas"])
+    assert np.array_equal(np.isfinite(ht), fin)
+    np.testing.assert_allclose(ht[fin], z["thetas"][fin], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(hl, z["logpost"], rtol=RTOL)
+    k = z["thetas"][:, :, -1]
+    assert k.min() == 0 and k.max() >= 7          # the fixture walks through many dimensions

@@ -74,6 +74,13 @@ int rmh_model_changepoint_create(const double *x, const double *y, int n, int k,
  * Cholesky factors, log_prior the constant log(sum(w exp(0))) of :54-62.  No gradient. */
 int rmh_model_mixture_create(const double *weights, const double *mu, const double *L, int ncomp,
                              int d, double log_prior, rmh_model_t *out);
+/* ChangepointRegression1D with a VARIABLE number of changepoints k <= kmax (the model's own
+ * log_prior / log_likelihood take any k, changepoint.py:106-160).  theta is the padded vector
+ * [cpx (kmax, +inf beyond k), cpv (kmax+1, 1.0 beyond k+1), sig, k]: d = 2 kmax + 3.
+ * Sampled by rmh_proposal_cprj_create (trans-dimensional moves); no gradient. */
+int rmh_model_changepoint_rj_create(const double *x, const double *y, int n, int kmax, double xmin,
+                                    double xmax, double lamb, double alpha, double beta,
+                                    rmh_model_t *out);
 int rmh_model_dim(rmh_model_t m, int *d);
 int rmh_model_free(rmh_model_t m);
 
@@ -96,6 +103,17 @@ int rmh_proposal_rw_create(const double *L, int d, double scale, rmh_proposal_t 
  * trans-dimensional branch (:56-71), which does not exist at fixed k: theta' = theta.
  * nblk = 0 returns to the full-vector random walk.  (Changepoint model, fused run only.) */
 int rmh_proposal_rw_set_blocks(rmh_proposal_t p, int nblk, const int *sizes, const double *pcum);
+/* ChangepointRegression1DProp(model, hscale) WITH its trans-dimensional branch,
+ * riemann/test_changepoint.py:18-73: chained uniforms pick the cpx / cpv / sig block random
+ * walk (pcum = P_cumprop_cpx, _cpv, _sig; covariances :36-41) and otherwise a birth (k = 0 or
+ * U > 0.5) or a death move on ChangepointRegression1D.add_changepoint / subtract_changepoint
+ * (models/changepoint.py:193-240) whose logqratio is log|det J| of the height map (:48-78;
+ * autograd in the reference, analytic here).  d = 2 kmax + 3 of the variable-k model; a
+ * birth at k = kmax is refused.  In the history the accept byte carries bit 0 = accepted and
+ * bits 1..3 = the move (0 cpx, 1 cpv, 2 sig, 3 birth, 4 death, 5 birth refused).  Fused run
+ * only.  Stream use: DESIGN.md. */
+int rmh_proposal_cprj_create(double hscale, const double *pcum, int d, rmh_proposal_t *out);
+int rmh_proposal_cprj_set_probs(rmh_proposal_t p, const double *pcum);
 /* pCN(C, rho), proposals/randomwalk.py:78-101.  L = cholesky(C).  (Gaussian, mixture and
  * logistic models.) */
 int rmh_proposal_pcn_create(const double *L, int d, double rho, rmh_proposal_t *out);

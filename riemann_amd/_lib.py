@@ -34,6 +34,7 @@ SIGNATURES = {
     "rmh_model_logreg_create": [_f64, _f64, _i64, _int, _dbl, _pvp],
     "rmh_model_changepoint_create": [_f64, _f64, _int, _int, _dbl, _dbl, _dbl, _dbl, _dbl, _pvp],
     "rmh_model_mixture_create": [_f64, _f64, _f64, _int, _int, _dbl, _pvp],
+    "rmh_model_changepoint_rj_create": [_f64, _f64, _int, _int, _dbl, _dbl, _dbl, _dbl, _dbl, _pvp],
     "rmh_model_dim": [_vp, C.POINTER(_int)],
     "rmh_model_free": [_vp],
     "rmh_log_prior": [_vp, _f64, _i64, _f64],
@@ -42,6 +43,8 @@ SIGNATURES = {
     "rmh_grad_log_posterior": [_vp, _f64, _i64, _f64],
     "rmh_proposal_rw_create": [_f64, _int, _dbl, _pvp],
     "rmh_proposal_rw_set_blocks": [_vp, _int, _i32, _f64],
+    "rmh_proposal_cprj_create": [_dbl, _f64, _int, _pvp],
+    "rmh_proposal_cprj_set_probs": [_vp, _f64],
     "rmh_proposal_set_adapt_cov": [_vp, _vp, _dbl, _int, _int, _int],
     "rmh_proposal_adapt_cov_get": [_vp, _f64],
     "rmh_proposal_adapt_cov_set": [_vp, _f64, _dbl],

@@ -141,6 +141,12 @@ int eval_states(rmh_model *m, const ChainArgs &c, bool want_grad, double *lp, do
     case kLogReg:
         e = launch_logreg_eval(m->NT, m->la, c, want_grad, lp, grad, lprior, llik, g_stream);
         break;
+    case kChangepointRJ:
+        if (want_grad)
+            return fail(RMH_ERR_PARAM, "the changepoint model has no gradient "
+                                       "(riemann/models/changepoint.py:108-113)");
+        e = launch_cprj_eval(m->rj, c, lprior, llik, lp, g_stream);
+        break;
     case kMixture:
         if (want_grad)
             return fail(RMH_ERR_PARAM, "MixtureDist has no gradient (riemann/models/benchmarks.py:31-62)");
@@ -511,6 +517,50 @@ int rmh_model_changepoint_create(const double *x, const double *y, int n, int k,
     return RMH_OK;
 }
 
+int rmh_model_changepoint_rj_create(const double *x, const double *y, int n, int kmax, double xmin,
+                                    double xmax, double lamb, double alpha, double beta,
+                                    rmh_model_t *out)
+{
+    RMH_NEED_INIT();
+    if (kmax < 1 || kmax > 14) return fail(RMH_ERR_PARAM, "changepoint: 1 <= kmax <= 14 supported");
+    if (n < 1 || n > 8192) return fail(RMH_ERR_PARAM, "changepoint: 1 <= n <= 8192 data points supported");
+    rmh_model *m = new rmh_model;
+    m->kind = kChangepointRJ;
+    m->k = kmax;
+    m->d = 2 * kmax + 3;
+    m->NT = nt_for_dim(m->d);
+    std::vector<double> xy((size_t)2 * n), kt((size_t)4 * (kmax + 2), 0.0);
+    for (int i = 0; i < n; ++i) {
+        xy[i] = x[i];
+        xy[n + i] = y[i];
+    }
+    for (int kp = 1; kp <= kmax + 1; ++kp) { // kp = pieces = len(theta.cpv), changepoint.py:133
+        kt[4 * kp + 0] = kp * std::log(lamb) - std::lgamma((double)kp) - lamb;   // :134
+        kt[4 * kp + 1] = std::lgamma(2.0 * kp + 1);                               // :143
+        kt[4 * kp + 2] = kp * std::log(xmax - xmin);
+        kt[4 * kp + 3] = std::sqrt(0.01 * (xmax - xmin) / kp);                    // test_changepoint.py:36
+    }
+    int rc;
+    if ((rc = upload(&m->d_xy, xy.data(), xy.size())) || (rc = upload(&m->d_ktab, kt.data(), kt.size()))) {
+        rmh_model_free(m);
+        return rc;
+    }
+    CpArgs &a = m->rj.base;
+    a.xy = m->d_xy;
+    a.n = n;
+    a.xmin = xmin;
+    a.xmax = xmax;
+    a.alpha_m1 = alpha - 1;
+    a.beta = beta;
+    a.c_v = alpha * std::log(beta);
+    a.lgam_alpha = std::lgamma(alpha);
+    a.nlog2pi = n * std::log(2 * M_PI);
+    m->rj.ktab = m->d_ktab;
+    m->rj.KM = kmax;
+    *out = m;
+    return RMH_OK;
+}
+
 int rmh_model_dim(rmh_model_t m, int *d)
 {
     if (!m) return fail(RMH_ERR_PARAM, "null model");
@@ -526,6 +576,7 @@ int rmh_model_free(rmh_model_t m)
     (void)hipFree(m->d_mu);
     (void)hipFree(m->d_X);
     (void)hipFree(m->d_xy);
+    (void)hipFree(m->d_ktab);
     (void)hipFree(m->d_mixW);
     (void)hipFree(m->d_mixmu);
     (void)hipFree(m->d_mixc);
@@ -619,6 +670,28 @@ int rmh_proposal_rw_set_blocks(rmh_proposal_t p, int nblk, const int *sizes, con
         p->blk_p[b] = b < nblk ? pcum[b] : 0.0;
     }
     p->nblk = nblk;
+    return RMH_OK;
+}
+
+int rmh_proposal_cprj_create(double hscale, const double *pcum, int d, rmh_proposal_t *out)
+{
+    RMH_NEED_INIT();
+    if (!pcum || !out || d < 5 || !(hscale > 0.0)) return fail(RMH_ERR_PARAM, "changepoint proposal: bad argument");
+    rmh_proposal *p = new rmh_proposal;
+    p->kind = kCpRJ;
+    p->d = d;
+    p->NT = nt_for_dim(d);
+    p->hscale = hscale;
+    for (int b = 0; b < 3; ++b) p->blk_p[b] = pcum[b];
+    p->dirty = false;
+    *out = p;
+    return RMH_OK;
+}
+
+int rmh_proposal_cprj_set_probs(rmh_proposal_t p, const double *pcum)
+{
+    if (!p || p->kind != kCpRJ || !pcum) return fail(RMH_ERR_PARAM, "not a trans-dimensional changepoint proposal");
+    for (int b = 0; b < 3; ++b) p->blk_p[b] = pcum[b];
     return RMH_OK;
 }
 
@@ -739,6 +812,7 @@ int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
 {
     RMH_NEED_INIT();
     if (!p || !theta || !rng || !theta_p || !logq || N < 1) return fail(RMH_ERR_PARAM, "bad argument");
+    if (p->kind == kCpRJ) return fail(RMH_ERR_PARAM, "propose: stand-alone trans-dimensional proposals are not built");
     if (p->kind == kHMC && !m) return fail(RMH_ERR_PARAM, "hmc: needs a device Model for the gradient");
     if (m && m->d != p->d)
         return fail(RMH_ERR_PARAM, "theta and L have incompatible shapes"); // randomwalk.py:24

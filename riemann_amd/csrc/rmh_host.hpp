@@ -27,6 +27,9 @@ struct rmh_model {
     int k = 0;
     double *d_xy = nullptr;
     rmh::CpArgs ca{};
+    // changepoint with a variable number of changepoints (capacity k): table by pieces
+    double *d_ktab = nullptr;
+    rmh::CpRjArgs rj{};
     // mixture of gaussians
     double *d_mixW = nullptr, *d_mixmu = nullptr, *d_mixc = nullptr, *d_mixw = nullptr;
     rmh::MixArgs ma{};
@@ -41,6 +44,7 @@ struct rmh_proposal {
     bool dirty = true;
     double *d_chM = nullptr, *d_V = nullptr, *d_VT = nullptr; // mass-matrix tile images (HMC)
     double minv = 1.0;                                        // M^-1 = minv (chM chM^T)^-1
+    double hscale = 0.0;                                      // ChangepointRegression1DProp (kCpRJ)
     int nblk = 0, blk_end[3] = {0, 0, 0};                     // block-mixture random walk
     double blk_p[3] = {0.0, 0.0, 0.0};
     // AdaptCovProposal (proposals/adaptive.py:38-103), pooled over the chains

@@ -6,8 +6,8 @@
 
 namespace rmh {
 
-enum ModelKind { kGauss = 1, kLogReg = 2, kChangepoint = 3, kMixture = 4 };
-enum ProposalKind { kRW = 1, kHMC = 2, kPCN = 3 };
+enum ModelKind { kGauss = 1, kLogReg = 2, kChangepoint = 3, kMixture = 4, kChangepointRJ = 5 };
+enum ProposalKind { kRW = 1, kHMC = 2, kPCN = 3, kCpRJ = 4 };
 
 // ---- device-side argument blocks (passed by value to the kernels) ----------
 struct GaussArgs {
@@ -50,6 +50,17 @@ struct CpArgs {
     double c_s;            // lgamma(2k'+1)
     double c_sL;           // k' log(xmax-xmin)
     double nlog2pi;        // n log(2 pi)
+};
+
+// Trans-dimensional changepoint sampling: model with a variable number
+// k <= KM of changepoints, state = padded vector [cpx (KM, +inf beyond k), cpv (KM+1, 1.0
+// beyond k+1), sig, k], and the proposal of riemann/test_changepoint.py:43-73.
+struct CpRjArgs {
+    CpArgs base;           // data and the k-independent constants (c_k, c_s, c_sL unused)
+    const double *ktab;    // (KM+2) x 4 by pieces k' = k+1: c_k, lgamma(2k'+1), k' log(xmax-xmin), sqrt(C_cpx(k))
+    int KM;                // capacity = the model's kmax
+    double sv, ss;         // sqrt(C_cpv), sqrt(C_sig) (test_changepoint.py:36-41), set by the proposal
+    double pcum[3];        // P_cumprop_cpx, _cpv, _sig
 };
 
 struct ChainArgs {
@@ -181,6 +192,9 @@ hipError_t launch_big_gauss_eval(int NT, const GaussArgs &m, const ChainArgs &c,
 // 1 AdaptScale random walk, 2 pCN, 3 AdaptScalepCN, 4 parallel tempering
 hipError_t launch_cp_generic(int k, const CpArgs &m, const RwArgs &p, const ChainArgs &c,
                              const RunArgs &r, int variant, hipStream_t st);
+hipError_t launch_cprj_eval(const CpRjArgs &m, const ChainArgs &c, double *lprior, double *llik,
+                            double *lpost, hipStream_t st);
+hipError_t launch_cprj_run(const CpRjArgs &m, const ChainArgs &c, const RunArgs &r, hipStream_t st);
 hipError_t launch_rng_seed(uint64_t *rng, int64_t ld, uint64_t seed, uint64_t chain0,
                            hipStream_t st);
 hipError_t launch_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const double *icdf,

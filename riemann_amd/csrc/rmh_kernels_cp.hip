@@ -336,6 +336,324 @@ static hipError_t cp_eval_launch(const CpArgs &m, const ChainArgs &c, double *a,
     return hipGetLastError();
 }
 
+// --------------------------------------------------------------------------------------
+// Trans-dimensional sampling over the number of changepoints:
+//   ChangepointRegression1DProp.propose WITH its birth/death branch,
+//   riemann/test_changepoint.py:43-73, on add_changepoint / subtract_changepoint,
+//   riemann/models/changepoint.py:193-240 (height map :48-69), and the model's
+//   log_prior / log_likelihood (:106-160) for any number of changepoints.
+// Same four-lanes-per-chain tile.  KD = compile-time size of the register arrays (6 or 14),
+// KM <= KD the capacity (the model's kmax) that fixes the padded layout
+//   [cpx (KM, +inf beyond k), cpv (KM+1, 1.0 beyond k+1), sig, k]
+// and the normals' coordinates (cpx_j: j, cpv_j: KM + j, sig: 2 KM + 1).  The normals are
+// parked in LDS so that "coordinate KM + j" is an address, not a register index.  Stream per
+// iteration: the normals, then two more words from every sub-stream -- (accept, U1, U2, U3)
+// and (U4, location, height split, index) -- see oracle/rmh_oracle.c section 6.
+// logqratio of a birth is log|det J| of (h, u) -> (h/f, h f), f = sqrt((1-u)/u): log(h / (u (1-u)))
+// (the reference differentiates the map with autograd), of a death its negative.
+template <int KD>
+struct CpRj {
+    static constexpr int KP = KD + 1;
+
+    // the padded state of one chain, replicated in its four lanes
+    struct State {
+        double cpx[KD], cpv[KP], sig;
+        int k;
+    };
+
+    static RMH_DEV double sel(const double (&a)[KP], int idx)
+    {
+        double v = reg(a[0]);
+#pragma unroll
+        for (int j = 1; j < KP; ++j) v = (idx == j) ? reg(a[j]) : v;
+        return v;
+    }
+
+    // log_prior for k changepoints (k' = k+1 pieces), changepoint.py:128-160
+    static RMH_DEV double log_prior(const CpRjArgs &m, const double *ktab, const State &s, int g)
+    {
+        const CpArgs &b = m.base;
+        double pv = 0.0, ps = 0.0;
+#pragma unroll
+        for (int j0 = 0; j0 < KP; j0 += 4) {
+            // lane g takes piece j0 + g (static indices through selects)
+            double v = 1.0, lo = b.xmin, hi = b.xmax;
+            const int j = j0 + g;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (j0 + q < KP && g == q) {
+                    v = s.cpv[j0 + q];
+                    lo = (j0 + q == 0) ? b.xmin : s.cpx[(j0 + q - 1 < KD && j0 + q >= 1) ? j0 + q - 1 : 0];
+                    hi = (j0 + q < KD) ? s.cpx[j0 + q < KD ? j0 + q : 0] : b.xmax;
+                }
+            }
+            const bool valid = j <= s.k;
+            if (j == s.k) hi = b.xmax; // the last piece ends at xmax (cpx beyond k is +inf)
+            const double vv = valid ? v : 1.0, dx = valid ? hi - lo : 1.0;
+            const double tv = ((b.c_v + b.alpha_m1 * log_full(vv)) - b.beta * vv) - b.lgam_alpha;
+            const double ts = log_full(dx);
+            pv += valid ? tv : 0.0;
+            ps += valid ? ts : 0.0;
+        }
+        pv = sum4(pv);
+        ps = sum4(ps);
+        const double *kt = ktab + 4 * (s.k + 1);
+        double p2 = log_full(1.0 / (s.sig * s.sig));
+        if (s.sig < 0.0) p2 = __builtin_nan("");
+        double logP = ((kt[0] + pv) + ((kt[1] + ps) - kt[2])) + p2;
+        if (logP != logP) logP = -__builtin_huge_val();
+        return logP;
+    }
+
+    template <bool SORTED>
+    static RMH_DEV double log_lik(const double *xy, const CpRjArgs &m, const State &s, int g)
+    {
+        const CpArgs &b = m.base;
+        const double sig2 = s.sig * s.sig;
+        double ss = 0.0;
+        for (int i = g; i < b.n; i += 4) {
+            const double x = xy[i], y = xy[b.n + i];
+            double v;
+            if (SORTED) { // cpx sorted (finite prior), +inf beyond k: cpv[#{cpx < x}]
+                v = reg(s.cpv[0]);
+#pragma unroll
+                for (int j = 0; j < KD; ++j) v = (s.cpx[j] < x) ? reg(s.cpv[j + 1]) : v;
+            } else { // numpy searchsorted on the first k entries, any order
+                int lo = 0, hi = s.k;
+#pragma unroll
+                for (int it = 0; it < 5; ++it) {
+                    if (lo < hi) {
+                        const int mid = lo + ((hi - lo) >> 1);
+                        double a = reg(s.cpx[0]);
+#pragma unroll
+                        for (int j = 1; j < KD; ++j) a = (mid == j) ? reg(s.cpx[j]) : a;
+                        if (a < x) lo = mid + 1; else hi = mid;
+                    }
+                }
+                v = sel(s.cpv, lo);
+            }
+            const double r = v - y;
+            ss += r * r;
+        }
+        ss = sum4(ss) / sig2;
+        double logL = -0.5 * ((ss + b.n * log_full(sig2)) + b.nlog2pi);
+        if (logL != logL) logL = -__builtin_huge_val();
+        return logL;
+    }
+
+    static RMH_DEV void load(const double *theta, int64_t ld, int64_t c, int KM, State &s)
+    {
+#pragma unroll
+        for (int j = 0; j < KD; ++j) s.cpx[j] = (j < KM) ? theta[(int64_t)j * ld + c] : __builtin_huge_val();
+#pragma unroll
+        for (int j = 0; j < KP; ++j) s.cpv[j] = (j <= KM) ? theta[(int64_t)(KM + j) * ld + c] : 1.0;
+        s.sig = theta[(int64_t)(2 * KM + 1) * ld + c];
+        s.k = (int)theta[(int64_t)(2 * KM + 2) * ld + c];
+    }
+
+    // rows of the padded layout; lane g stores rows = g (mod 4)
+    static RMH_DEV void store(double *dst, int64_t ld, int64_t c, int KM, int g, const State &s)
+    {
+#pragma unroll
+        for (int j = 0; j < KD; ++j)
+            if (j < KM && (j & 3) == g) dst[(int64_t)j * ld + c] = s.cpx[j];
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+            if (j <= KM && ((KM + j) & 3) == g) dst[(int64_t)(KM + j) * ld + c] = s.cpv[j];
+        if (((2 * KM + 1) & 3) == g) dst[(int64_t)(2 * KM + 1) * ld + c] = s.sig;
+        if (((2 * KM + 2) & 3) == g) dst[(int64_t)(2 * KM + 2) * ld + c] = (double)s.k;
+    }
+};
+
+template <int KD>
+__global__ void __launch_bounds__(256) k_cprj_run(CpRjArgs m, ChainArgs ch, RunArgs run)
+{
+    using R = CpRj<KD>;
+    constexpr int KP = KD + 1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int KM = m.KM, Dn = 2 * KM + 2, n = m.base.n;
+    double *xy = lds;                              // x[n], y[n]
+    double *ktab = lds + 2 * n;                    // (KM+2) x 4
+    double *tab = ktab + 4 * (KM + 2);             // inverse-CDF table (16-byte aligned: n even or padded by the host)
+    double *xi_all = tab + kIcdfDoubles;           // per wave: 16 chains x 32 coordinates
+    for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) xy[i] = m.base.xy[i];
+    for (int i = threadIdx.x; i < 4 * (KM + 2); i += blockDim.x) ktab[i] = m.ktab[i];
+    icdf_stage(tab, ch.icdf);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, g = lane >> 4;
+    const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (blk >= ch.nblocks) return;
+    const int64_t c = blk * 16 + cl, slot = blk * 64 + lane;
+    double *xw = xi_all + wave * (16 * 32) + cl * 32;   // this chain's normals by coordinate
+
+    typename R::State th;
+    R::load(ch.theta, ch.ld, c, KM, th);
+    double lp = ch.logpost[c];
+    Xo rng = xo_load(ch.rng, ch.nslots, slot);
+    const int rows = 4 * ch.ks;
+
+    int64_t knext = run.nburn, kentry = 0;
+    auto rec = [&](int64_t e) {
+        if (e != knext) return;
+        knext += run.nthin;
+        const int64_t kk = kentry++;
+        if (!run.h_theta) return;
+        R::store(run.h_theta + kk * (int64_t)rows * ch.ld, ch.ld, c, KM, g, th);
+        if (g == 0) run.h_logpost[kk * ch.ld + c] = lp;
+    };
+    rec(0);
+
+    for (int64_t t = 0; t < run.T; ++t) {
+        asm volatile("" ::: "memory");
+        // normals of the padded coordinates: word mm of sub-stream g is coordinate 4 mm + g
+        for (int mm = 0; mm < (Dn + 3) / 4; ++mm) { // the normals cover the 2 KM + 2 padded coordinates
+            const double z = normal_from_word(xo_next(rng), tab);
+            if (4 * mm + g < Dn) xw[4 * mm + g] = z;
+        }
+        const double w1 = u01(xo_next(rng)), w2 = u01(xo_next(rng));
+        const double uacc = __shfl(w1, cl), U1 = __shfl(w1, 16 + cl), U2 = __shfl(w1, 32 + cl), U3 = __shfl(w1, 48 + cl);
+        const double U4 = __shfl(w2, cl), us = __shfl(w2, 16 + cl), uu = __shfl(w2, 32 + cl), un = __shfl(w2, 48 + cl);
+        __builtin_amdgcn_wave_barrier(); // the wave's LDS writes above are read below (same wave: in order)
+
+        typename R::State tp = th;
+        double logq = 0.0;
+        int mv;
+        const int k = th.k;
+        if (U1 < m.pcum[0]) { // cpx block, test_changepoint.py:47-49
+            mv = 0;
+            const double sx = ktab[4 * (k + 1) + 3];
+#pragma unroll
+            for (int j = 0; j < KD; ++j)
+                if (j < k) tp.cpx[j] = th.cpx[j] + sx * xw[j];
+        } else if (U2 < m.pcum[1]) { // cpv block, :50-52
+            mv = 1;
+#pragma unroll
+            for (int j = 0; j < KP; ++j)
+                if (j <= k) tp.cpv[j] = th.cpv[j] + m.sv * xw[KM + j];
+        } else if (U3 < m.pcum[2]) { // sig, :53-55
+            mv = 2;
+            tp.sig = th.sig + m.ss * xw[2 * KM + 1];
+        } else if (k == 0 || U4 > 0.5) { // birth, :58-63, changepoint.py:193-218
+            mv = 3;
+            const double s = m.base.xmin + (m.base.xmax - m.base.xmin) * us;
+            const double u = 0.5 + (-0.1 + 0.2 * uu) / sqrt((double)n);
+            if (k >= KM) {
+                mv = 5; // no room: refused
+            } else {
+                int nn = 0;
+#pragma unroll
+                for (int j = 0; j < KD; ++j) nn += (th.cpx[j] < s) ? 1 : 0; // +inf beyond k
+                const double h = R::sel(th.cpv, nn), ufac = sqrt((1.0 - u) / u);
+                const double h1 = h / ufac, h2 = h * ufac;
+#pragma unroll
+                for (int j = 0; j < KD; ++j)
+                    tp.cpx[j] = (j < nn) ? th.cpx[j] : (j == nn) ? s : th.cpx[j > 0 ? j - 1 : 0];
+#pragma unroll
+                for (int j = 0; j < KP; ++j)
+                    tp.cpv[j] = (j < nn) ? th.cpv[j] : (j == nn) ? h1 : (j == nn + 1) ? h2 : th.cpv[j > 0 ? j - 1 : 0];
+                tp.k = k + 1;
+                logq = log_full(__builtin_fabs(h / (u * (1.0 - u))));
+            }
+        } else { // death, :65-71, changepoint.py:220-240
+            mv = 4;
+            int nn = (int)(un * k);
+            nn = nn >= k ? k - 1 : nn;
+            const double h1 = R::sel(th.cpv, nn), h2 = R::sel(th.cpv, nn + 1);
+            const double h = sqrt(h1 * h2), u = 1.0 / (1.0 + h2 / h1);
+#pragma unroll
+            for (int j = 0; j < KD; ++j)
+                tp.cpx[j] = (j < nn) ? th.cpx[j] : (j + 1 < KD ? th.cpx[j + 1 < KD ? j + 1 : 0] : __builtin_huge_val());
+#pragma unroll
+            for (int j = 0; j < KP; ++j)
+                tp.cpv[j] = (j < nn) ? th.cpv[j] : (j == nn) ? h : (j + 1 < KP ? th.cpv[j + 1 < KP ? j + 1 : 0] : 1.0);
+            tp.k = k - 1;
+            logq = log_full(__builtin_fabs(u * (1.0 - u) / h));
+        }
+        double lpp = -__builtin_huge_val();
+        if (mv != 5) {
+            const double logP = R::log_prior(m, ktab, tp, g);
+            if (__any(logP > -__builtin_huge_val())) {
+                const double logL = R::template log_lik<true>(xy, m, tp, g);
+                lpp = combine_post(logP, logL);
+            }
+        }
+        const bool ok = mh_accept(lpp, lp, logq, uacc);
+        if (ok) {
+            th = tp;
+            lp = lpp;
+        }
+        // accept byte: bit 0 accepted, bits 1..3 the move (0 cpx, 1 cpv, 2 sig, 3 birth, 4 death, 5 refused)
+        if (run.h_accept && g == 0) run.h_accept[t * ch.ld + c] = (uint8_t)((ok ? 1 : 0) | (mv << 1));
+        rec(t + 1);
+    }
+    R::store(ch.theta, ch.ld, c, KM, g, th);
+    if (g == 0) ch.logpost[c] = lp;
+    xo_store(ch.rng, ch.nslots, slot, rng);
+}
+
+template <int KD>
+__global__ void __launch_bounds__(256) k_cprj_eval(CpRjArgs m, ChainArgs ch, double *lprior, double *llik,
+                                                   double *lpost)
+{
+    using R = CpRj<KD>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = m.base.n, KM = m.KM;
+    double *xy = lds, *ktab = lds + 2 * n;
+    for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) xy[i] = m.base.xy[i];
+    for (int i = threadIdx.x; i < 4 * (KM + 2); i += blockDim.x) ktab[i] = m.ktab[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, g = lane >> 4;
+    const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (blk >= ch.nblocks) return;
+    const int64_t c = blk * 16 + cl;
+    typename R::State th;
+    R::load(ch.theta, ch.ld, c, KM, th);
+    th.k = th.k < 0 ? 0 : th.k > KM ? KM : th.k;
+    const double logP = R::log_prior(m, ktab, th, g);
+    const double logL = R::template log_lik<false>(xy, m, th, g);
+    if (g == 0) {
+        if (lprior) lprior[c] = logP;
+        if (llik) llik[c] = logL;
+        if (lpost) lpost[c] = combine_post(logP, logL);
+    }
+}
+
+hipError_t launch_cprj_run(const CpRjArgs &m, const ChainArgs &c, const RunArgs &r, hipStream_t st)
+{
+    const int nev = (2 * m.base.n + 4 * (m.KM + 2) + 1) & ~1; // keep the table 16-byte aligned
+    (void)nev;
+    const size_t lds = sizeof(double) * ((size_t)2 * m.base.n + 4 * (m.KM + 2) + kIcdfDoubles + 4 * 16 * 32);
+    const dim3 grid((unsigned)((c.nblocks + 3) / 4)), block(256);
+    if (m.KM <= 6) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cprj_run<6>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_cprj_run<6>, grid, block, lds, st, m, c, r);
+    } else if (m.KM <= 14) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cprj_run<14>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_cprj_run<14>, grid, block, lds, st, m, c, r);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_cprj_eval(const CpRjArgs &m, const ChainArgs &c, double *lprior, double *llik,
+                            double *lpost, hipStream_t st)
+{
+    const size_t lds = sizeof(double) * ((size_t)2 * m.base.n + 4 * (m.KM + 2));
+    const dim3 grid((unsigned)((c.nblocks + 3) / 4)), block(256);
+    if (m.KM <= 6) hipLaunchKernelGGL(k_cprj_eval<6>, grid, block, lds, st, m, c, lprior, llik, lpost);
+    else if (m.KM <= 14) hipLaunchKernelGGL(k_cprj_eval<14>, grid, block, lds, st, m, c, lprior, llik, lpost);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 #define RMH_CP_DISPATCH(fn, ...)                       \
     switch (k) {                                       \
     case 1: return fn<1>(__VA_ARGS__);                 \

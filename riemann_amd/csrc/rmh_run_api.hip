@@ -327,7 +327,16 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
     RMH_HIP(hipEventRecord(g_ev0, g_stream));
     hipError_t e = hipSuccess;
     int launches = 1;
-    if (m->big) { // 112 < d <= 896
+    if (p->kind == kCpRJ || m->kind == kChangepointRJ) { // trans-dimensional changepoint sampling
+        if (p->kind != kCpRJ || m->kind != kChangepointRJ || adapt || K > 0)
+            return fail(RMH_ERR_PARAM, "run: the variable-k changepoint model goes with "
+                                       "ChangepointRegression1DProp (and nothing else)");
+        CpRjArgs ra = m->rj;
+        ra.sv = std::sqrt(0.01 * p->hscale * p->hscale / ra.base.n);   // test_changepoint.py:37
+        ra.ss = std::sqrt(0.01 * p->hscale);                            // :38
+        for (int b = 0; b < 3; ++b) ra.pcum[b] = p->blk_p[b];
+        e = launch_cprj_run(ra, c, r, g_stream);
+    } else if (m->big) { // 112 < d <= 896
         if (p->kind != kRW || adapt || K > 0 || p->acov || p->nblk > 0)
             return fail(RMH_ERR_PARAM, "run: for d > 112 only the plain random walk on the Gaussian model is built");
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};

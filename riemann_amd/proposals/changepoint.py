@@ -20,6 +20,9 @@ class ChangepointRegression1DProp(MetropolisRandomWalk):
     (set ``P_cumprop_sig = 1.0`` for a pure fixed-k sampler)."""
 
     def __init__(self, model, hscale):
+        if getattr(model, "variable_k", False):
+            self._init_trans_dimensional(model, hscale)
+            return
         self.model = model
         self.Ndata = len(model.x)
         self.hscale = hscale
@@ -41,7 +44,26 @@ class ChangepointRegression1DProp(MetropolisRandomWalk):
         self._sizes = np.array([k, k + 1, 1], dtype=np.int32)
         self._sync()
 
+    def _init_trans_dimensional(self, model, hscale):
+        """On a ``variable_k=True`` model: the whole proposal of test_changepoint.py:43-73,
+        birth / death moves included (``P_cumprop_dim`` is what remains after the three
+        blocks); the block covariances follow the chain's current k (:34-41)."""
+        import ctypes as C
+        self.model, self.Ndata, self.hscale = model, len(model.x), hscale
+        self.P_cumprop_cpx, self.P_cumprop_cpv, self.P_cumprop_sig, self.P_cumprop_dim = 0.20, 0.40, 0.60, 1.00
+        self.k = None
+        self.scale = 1.0
+        self.Npars = model.Npars
+        self._rj = True
+        h = C.c_void_p()
+        _lib.call("rmh_proposal_cprj_create", float(hscale), _lib.as_f64(
+            [self.P_cumprop_cpx, self.P_cumprop_cpv, self.P_cumprop_sig]), self.Npars, C.byref(h))
+        self._h = h
+
     def _sync(self):
-        MetropolisRandomWalk._sync(self)
         pcum = _lib.as_f64([self.P_cumprop_cpx, self.P_cumprop_cpv, self.P_cumprop_sig])
+        if getattr(self, "_rj", False):
+            _lib.call("rmh_proposal_cprj_set_probs", self._h, pcum)
+            return
+        MetropolisRandomWalk._sync(self)
         _lib.call("rmh_proposal_rw_set_blocks", self._h, 3, self._sizes, pcum)

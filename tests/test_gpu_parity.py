@@ -1340,3 +1340,71 @@ def test_run_to_disk_streams_the_same_samples(ra, tmp_path):
         else:
             with pytest.raises(IndexError):
                 b.current_state()
+
+
+# ----------------------------- trans-dimensional changepoint sampling (8f-4)
+def rj_model(z):
+    from riemann_amd.models import ChangepointRegression1D
+    return ChangepointRegression1D(z["x"], z["y"], float(z["xmin"]), float(z["xmax"]), float(z["lamb"]),
+                                   int(z["KM"]), float(z["alpha"]), float(z["beta"]), variable_k=True)
+
+
+def test_g17_trans_dimensional_changepoint_sampler_vs_reference_fixture(ra):
+    """The reference's ChangepointRegression1DProp with its birth/death branch: moves, accepts,
+    the number of changepoints and the states of 4 chains x 300 iterations."""
+    from riemann_amd.proposals import ChangepointRegression1DProp
+    z = load("g17_changepoint_rj")
+    m = rj_model(z)
+    start = m.unpack_padded(z["theta0"])
+    np.testing.assert_array_equal(m.pack_padded(start), z["theta0"])
+    np.testing.assert_allclose(m.log_posterior(z["theta0"]), z["logpost"][0], rtol=RTOL)
+    p = ChangepointRegression1DProp(m, float(z["hscale"]))
+    assert p.P_cumprop_dim == 1.0
+    p.P_cumprop_sig = 0.0                    # as the fixture (the reference's sig block raises under numpy 2)
+    s = ra.Sampler(m, p, start, seed=int(z["seed"]))
+    s.run(300)
+    code = s._chain_accept
+    np.testing.assert_array_equal(code >> 1, z["move"])
+    np.testing.assert_array_equal(code & 1, z["accept"])
+    th = s._chain_thetas
+    np.testing.assert_array_equal(th[:, :, -1], z["thetas"][:, :, -1])
+    fin = np.isfinite(z["thetas"])
+    assert np.array_equal(np.isfinite(th), fin)
+    np.testing.assert_allclose(th[fin], z["thetas"][fin], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(s._chain_logpost, z["logpost"], rtol=RTOL)
+    last = m.unpack_padded(th[-1])
+    assert [len(t.cpx) for t in last] == list(z["thetas"][-1, :, -1].astype(int))
+
+
+@pytest.mark.parametrize("KM,N", [(5, 3000), (12, 1000)])
+def test_trans_dimensional_changepoint_many_chains_vs_oracle(ra, orc, KM, N):
+    """Default probabilities (all five move types, births refused at capacity) on many chains."""
+    from riemann_amd import workloads as W
+    from riemann_amd.models import ChangepointRegression1D
+    from riemann_amd.proposals import ChangepointRegression1DProp
+    x, y, truth, cdiag = W.changepoint_data()
+    m = ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, KM, 1, 1, variable_k=True)
+    om = orc.Changepoint(x, y, 1, 1.0, 3.0, 5.0, 1.0, 1.0)
+    g = np.random.default_rng(KM)
+    starts = []
+    for c in range(N):
+        k = int(g.integers(0, KM + 1))
+        starts.append((np.sort(g.uniform(1.05, 2.95, size=k)), g.uniform(1.0, 3.0, size=k + 1), float(g.uniform(0.2, 1.0))))
+    th0 = orc.cprj_pack(starts, KM)
+    p = ChangepointRegression1DProp(m, 2.0)
+    s = ra.Sampler(m, p, th0, seed=6, chain0=160)
+    T = 80
+    s.run(T)
+    th = th0.copy()
+    lp = orc.cprj_log_posterior(om, KM, th)
+    ht, hl, acc, mv = orc.run_cprj(om, KM, 2.0, [0.2, 0.4, 0.6], th, lp, orc.rng_seed(6, N, chain0=160), T)
+    code = s._chain_accept
+    np.testing.assert_array_equal(code >> 1, mv)
+    np.testing.assert_array_equal(code & 1, acc)
+    got = s._chain_thetas
+    fin = np.isfinite(ht)
+    assert np.array_equal(np.isfinite(got), fin)
+    np.testing.assert_allclose(got[fin], ht[fin], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(s._chain_logpost, hl, rtol=RTOL)
+    assert set(np.unique(mv)) >= {0, 1, 2, 3, 4} and (mv == 5).any()
+    assert (acc[mv == 3] == 1).sum() > 20 and (acc[mv == 4] == 1).sum() > 20

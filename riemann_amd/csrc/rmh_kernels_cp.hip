@@ -348,7 +348,7 @@ static hipError_t cp_eval_launch(const CpArgs &m, const ChainArgs &c, double *a,
 // and the normals' coordinates (cpx_j: j, cpv_j: KM + j, sig: 2 KM + 1).  The normals are
 // parked in LDS so that "coordinate KM + j" is an address, not a register index.  Stream per
 // iteration: the normals, then two more words from every sub-stream -- (accept, U1, U2, U3)
-// and (U4, location, height split, index) -- see oracle/rmh_oracle.c section 6.
+// and (U4, location, height split, index) -- DESIGN.md, "Trans-dimensional changepoint sampling".
 // logqratio of a birth is log|det J| of (h, u) -> (h/f, h f), f = sqrt((1-u)/u): log(h / (u (1-u)))
 // (the reference differentiates the map with autograd), of a death its negative.
 template <int KD>

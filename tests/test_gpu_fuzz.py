@@ -17,7 +17,7 @@ def test_random_configurations_vs_oracle():
     spec.loader.exec_module(fz)
     g = np.random.default_rng(2026)
     seen = set()
-    for it in range(120):
+    for it in range(140):
         desc = fz.one(g, it)
         seen.add((desc.split()[0], desc.split("|")[0].split()[-1]))
-    assert {k for k, _ in seen} == {"gauss", "logreg", "mix", "cp", "bigd"}    # every model family came up
+    assert {k for k, _ in seen} == {"gauss", "logreg", "mix", "cp", "bigd", "cprj"}    # every model family came up

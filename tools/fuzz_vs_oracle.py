@@ -21,8 +21,55 @@ def spd(g, d, lo=0.3):
     return A @ A.T / d + lo * np.eye(d)
 
 
+def one_cprj(g):
+    """trans-dimensional changepoint sampling: random capacity, data, start dimensions, move mix"""
+    KM = int(g.integers(1, 15))
+    N = int(g.choice([1, 15, 16, 17, 100, int(g.integers(1, 400))]))
+    T = int(g.integers(0, 40))
+    n = int(g.choice([3, 24, 100, 101]))
+    x = np.sort(g.uniform(1.0, 3.0, size=n))
+    y = g.uniform(1.0, 3.0, size=n)
+    al, be = (1.0, 1.0) if g.uniform() < 0.5 else (2.5, 1.5)
+    lamb = float(g.uniform(1.0, 8.0))
+    m = ChangepointRegression1D(x, y, 1.0, 3.0, lamb, KM, al, be, variable_k=True)
+    om = orc.Changepoint(x, y, 1, 1.0, 3.0, lamb, al, be)
+    starts = []
+    for c in range(N):
+        k = int(g.integers(0, KM + 1))
+        starts.append((np.sort(g.uniform(1.05, 2.95, size=k)), g.uniform(0.5, 3.0, size=k + 1), float(g.uniform(0.2, 1.0))))
+    th0 = orc.cprj_pack(starts, KM)
+    pc = sorted(float(v) for v in g.uniform(0, 1, size=3)) if g.uniform() < 0.5 else [0.2, 0.4, 0.6]
+    hs = float(g.uniform(0.5, 3.0))
+    p = P.ChangepointRegression1DProp(m, hs)
+    p.P_cumprop_cpx, p.P_cumprop_cpv, p.P_cumprop_sig = pc
+    seed = int(g.integers(0, 2 ** 31))
+    desc = "cprj KM=%d N=%d T=%d n=%d" % (KM, N, T, n)
+    s = ra.Sampler(m, p, th0, seed=seed)
+    T1 = int(g.integers(0, T + 1))
+    s.run(T1)
+    first = (s._chain_thetas.copy(), s._chain_logpost.copy(), s._chain_accept.copy())
+    s.run(T - T1)
+    th = th0.copy()
+    lp = orc.cprj_log_posterior(om, KM, th)
+    np.testing.assert_allclose(m.log_posterior(th0), lp, rtol=1e-8, atol=1e-10, err_msg=desc + " eval")
+    ht, hl, acc, mv = orc.run_cprj(om, KM, hs, pc, th, lp, orc.rng_seed(seed, N), T)
+    code = np.concatenate([first[2], s._chain_accept])
+    got = np.concatenate([first[0], s._chain_thetas[1:]])
+    glp = np.concatenate([first[1], s._chain_logpost[1:]])
+    assert np.array_equal(code >> 1, mv) and np.array_equal(code & 1, acc), desc + " moves/accepts"
+    fin = np.isfinite(ht)
+    assert np.array_equal(np.isfinite(got), fin), desc + " finite"
+    np.testing.assert_allclose(got[fin], ht[fin], rtol=1e-8, atol=1e-11, err_msg=desc)
+    fl = np.isfinite(hl)
+    assert np.array_equal(np.isfinite(glp), fl), desc + " finite lp"
+    np.testing.assert_allclose(glp[fl], hl[fl], rtol=1e-8, atol=1e-10, err_msg=desc)
+    return desc + " cprj"
+
+
 def one(g, it):
-    kind = g.choice(["gauss", "gauss", "logreg", "mix", "cp", "bigd"])
+    kind = g.choice(["gauss", "gauss", "logreg", "mix", "cp", "bigd", "cprj"])
+    if kind == "cprj":
+        return one_cprj(g)
     dmax = {"gauss": 112, "logreg": 112, "mix": 40, "cp": 18, "bigd": 896}[kind]
     d = int(g.choice([1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 111, 112, int(g.integers(1, 113))]))
     d = min(d, dmax)

@@ -977,9 +977,9 @@ int orc_run_pt(const orc_model *m, const orc_proposal *p, int64_t S, double *the
                double *hist_theta, double *hist_logpost, uint8_t *code)
 {
     const int d = m->d;
-    if (p->d != d || p->kind != ORC_RW || K < 1 || K > 16 || (S & 15)) return -1;
+    if (p->d != d || (p->kind != ORC_RW && p->kind != ORC_HMC) || K < 1 || K > 16 || (S & 15)) return -1;
     const int EPW = 16 / K;
-    double *work = (double *)malloc(sizeof(double) * d * 6);
+    double *work = (double *)malloc(sizeof(double) * d * 8);
     double *xi = work, *thp = work + d, *w2 = work + 2 * d;
     double *lP = (double *)malloc(sizeof(double) * S), *lL = (double *)malloc(sizeof(double) * S);
     for (int64_t c = 0; c < S; c++) { /* Sampler.__init__ of every rung, sampler.py:42 */
@@ -1011,10 +1011,12 @@ int orc_run_pt(const orc_model *m, const orc_proposal *p, int64_t S, double *the
                     }
                     double *th = theta + c * d;
                     if (usel > pswap || i == K - 1) { /* within-chain step, Sampler.sample */
-                        orc_propose1(p, m, th, xi, thp, w2, 1.0);
+                        /* the proposal is the SAME object for every rung (ptsampler.py:82): an HMC
+                         * proposal integrates with the base model's gradient whatever the rung */
+                        const double logq = orc_propose1(p, m, th, xi, thp, w2, 1.0);
                         const double pP = orc_log_prior1(m, thp), pL = orc_log_lik1(m, thp, w2);
                         const double lpp = orc_tempered(pP, pL, betas[i]);
-                        const double delta = lpp - logpost[c] - 0.0;
+                        const double delta = lpp - logpost[c] - logq;
                         const double mh = (delta < 0) ? delta : 0.0;
                         if (orc_log(ua) < mh) {
                             memcpy(th, thp, sizeof(double) * d);

@@ -272,7 +272,12 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
 // MASS: VanillaHMC with a mass matrix M (hamiltonian.py:71-74, 80-81, 29, 36, 85-87):
 // p = chM xi;  q += eps M^-1 p with M^-1 p = V^T (V p), V = chM^-1;  K = |V p|^2 / 2.
 // The three triangular tile images are read straight from global memory (L2).
-template <class M, int NW, bool ADAPT, bool MASS>
+// PT: parallel tempering with HMC within-chain moves (see k_run_rw).  As in the reference the
+// proposal integrates with the gradient callable it was given -- the BASE model's, whatever
+// the rung (samplers/ptsampler.py:82 hands every rung the same proposal) -- and only the accept
+// test sees the tempered posterior.  A swap exchanges the two replicas' states and cached
+// gradients in global memory.
+template <class M, int NW, bool ADAPT, bool MASS, bool PT = false>
 __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs pr, ChainArgs ch, RunArgs run)
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
@@ -300,10 +305,44 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
     Keep keep(run);
     AdaptScale ad{0.0, 0.0, 1.0};
     if (ADAPT) ad.load(ch, c);
+    int rung = 0, ebase = 0;
+    bool pt_valid = false;
+    double beta = 1.0, sP = 0.0, sL = 0.0;
+    if (PT) {
+        const int K = run.pt_K;
+        rung = cl % K;
+        ebase = cl - rung;
+        pt_valid = cl < (16 / K) * K;
+        beta = run.pt_beta[c];
+        double q0[S], g0[S], lp0, parts0[2];
+        T::load_state(ch.theta, ch.ld, c, g, q0);
+        M::template eval<true, true>(lds, m, true, lane, q0, lp0, g0, parts0);
+        sP = parts0[0];
+        sL = parts0[1];
+        lp = combine_post(sP, beta * sL);   // Sampler.__init__ of the rung, sampler.py:42
+    }
 
     for (int64_t t = 0; t <= run.T; ++t) {
         asm volatile("" ::: "memory"); // no LICM of the LDS tile reads (see k_run_rw)
         double p[S], q[S], gr[S], lpp = 0.0, parts[2];
+        bool pt_init = false, pt_partner = false;
+        double vswap = 0.0;
+        if (PT && t < run.T) { // selector / swap words, then the sequential rule of ptsampler.py:104-109
+            const double uw = u01(xo_next(rng));
+            const double usel = __shfl(uw, cl);
+            vswap = __shfl(uw, 16 + cl);
+            const bool wants = pt_valid && rung < run.pt_K - 1 && !(usel > run.pt_pswap);
+            const unsigned wm = (unsigned)(__ballot(wants) & 0xFFFFu) >> ebase;
+            bool prev = false;
+            for (int j = 0; j < run.pt_K; ++j) {
+                const bool in = ((wm >> j) & 1u) && !prev;
+                if (j == rung) {
+                    pt_init = in;
+                    pt_partner = prev;
+                }
+                prev = in;
+            }
+        }
         if (t < run.T) T::normals(rng, ch.M, ch.d, g, tab, p);
         T::load_state(ch.theta, ch.ld, c, g, q);
         keep.record<NT>(run, ch, t, c, g, active, q, lp);
@@ -367,7 +406,9 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
         for (int s = 0; s < S; ++s) k1 += p[s] * p[s];
         const double logq = 0.5 * (sum4(k1) - sum4(k0)); // :89
         const double u = T::accept_uniform(rng, g, cl);
-        const bool acc_ok = mh_accept(lpp, lp, logq, u);
+        if (PT) lpp = combine_post(parts[0], beta * parts[1]); // TemperedModel, ptsampler.py:35-39
+        bool acc_ok = mh_accept(lpp, lp, logq, u);
+        if (PT) acc_ok = acc_ok && pt_valid && !pt_init && !pt_partner;
         if (acc_ok) {
             if (active) {
                 T::store_state(ch.theta, ch.ld, c, g, q);
@@ -375,8 +416,41 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
             }
             lp = lpp;
         }
+        int code = acc_ok ? 1 : 0;
+        if (PT) {
+            sP = acc_ok ? parts[0] : sP;
+            sL = acc_ok ? parts[1] : sL;
+            const bool swapper = pt_init || pt_partner;
+            const int src = pt_init ? lane + 1 : pt_partner ? lane - 1 : lane;
+            const double oP = __shfl(sP, src), oL = __shfl(sL, src), ob = __shfl(beta, src);
+            const double olp = __shfl(lp, src), ov = __shfl(vswap, src);
+            const double cross_me = combine_post(oP, beta * oL);
+            const double cross_ot = combine_post(sP, ob * sL);
+            const double delta = (cross_ot + cross_me) - (pt_init ? lp + olp : olp + lp);
+            const bool sw_ok = swapper && mh_accept(delta, 0.0, 0.0, pt_partner ? ov : vswap);
+            if (__any(sw_ok)) { // exchange state and cached gradient of the two replicas
+                asm volatile("" ::: "memory");
+                T::load_state(ch.theta, ch.ld, c, g, q);
+                T::load_state(ch.grad, ch.ld, c, g, gr);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const double oq = __shfl(q[s], src), og = __shfl(gr[s], src);
+                    q[s] = sw_ok ? oq : q[s];
+                    gr[s] = sw_ok ? og : gr[s];
+                }
+                if (active) {
+                    T::store_state(ch.theta, ch.ld, c, g, q);
+                    T::store_state(ch.grad, ch.ld, c, g, gr);
+                }
+                asm volatile("" ::: "memory");
+            }
+            sP = sw_ok ? oP : sP;
+            sL = sw_ok ? oL : sL;
+            lp = sw_ok ? cross_me : lp;
+            code = swapper ? (sw_ok ? 3 : 2) : code;
+        }
         if (ADAPT) ad.adapt(acc_ok, ch.adapt_target);
-        if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = acc_ok ? 1 : 0;
+        if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = (uint8_t)code;
     }
     if (active) {
         if (g == 0) ch.logpost[c] = lp;

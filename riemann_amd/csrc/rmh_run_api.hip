@@ -312,8 +312,11 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
     r.h_logpost = h ? h->logpost : nullptr;
     r.h_accept = h ? h->accept : nullptr;
     if (K > 0) { // parallel tempering: the slots' inverse temperatures
-        if (p->kind != kRW || adapt)
-            return fail(RMH_ERR_PARAM, "run_pt: built for MetropolisRandomWalk within-chain moves only");
+        if ((p->kind != kRW && p->kind != kHMC) || adapt || p->acov || p->nblk > 0 || (p->kind == kHMC && p->d_chM))
+            return fail(RMH_ERR_PARAM, "run_pt: built for MetropolisRandomWalk and VanillaHMC / MALA (no mass matrix, "
+                                       "no adaptation) within-chain moves");
+        if (p->kind == kHMC && m->kind != kGauss && m->kind != kLogReg)
+            return fail(RMH_ERR_PARAM, "run_pt: this model has no gradient");
         std::vector<double> b((size_t)s->ld, 1.0);
         const int used = (16 / K) * K;
         for (int64_t c0 = 0; c0 < s->ld; ++c0)
@@ -349,6 +352,10 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
                                        "and logistic models");
         launches = 0;
         if ((rc = run_adaptcov(m, p, s, c, T, nburn, nthin, h, &launches))) return rc;
+    } else if (K > 0 && p->kind == kHMC) {
+        HmcArgs ha{p->eps, p->nsteps, nullptr, nullptr, nullptr, 1.0};
+        e = m->kind == kGauss ? launch_gauss_hmc(m->NT, m->ga, ha, c, r, false, g_stream)
+                              : launch_logreg_hmc(m->NT, m->la, ha, c, r, false, g_stream);
     } else if (K > 0) {
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
         e = m->kind == kGauss         ? launch_gauss_pt(m->NT, m->ga, ra, c, r, g_stream)

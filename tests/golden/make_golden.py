@@ -542,6 +542,12 @@ def g12_pt():
                          rng.standard_normal((4, 2)), seed=120, T=96, pswap=0.3)
     save("g12_pt_gauss2d", mu=np.zeros(2), C=0.1 * np.eye(2) + 0.9 * np.ones((2, 2)),
          Cprop=0.5 * np.eye(2), **r)
+    # HMC within the rungs: the one proposal object serves every rung (ptsampler.py:82), so the
+    # trajectories use the BASE model's gradient and only the accept test is tempered
+    r = run_reference_pt(m, lambda: VanillaHMC(0.35, 3, m.grad_log_likelihood),
+                         rng.standard_normal((3, 2)), seed=122, T=96, pswap=0.3)
+    save("g12_pt_hmc_gauss2d", mu=np.zeros(2), C=0.1 * np.eye(2) + 0.9 * np.ones((2, 2)),
+         eps=np.float64(0.35), nsteps=np.int64(3), **r)
     mx = rbench.benchmark_gauss2d_mix2_cross
     r = run_reference_pt(mx, lambda: MetropolisRandomWalk(1.5 * np.eye(2)),
                          rng.standard_normal((3, 2)) * 2.0, seed=121, T=96, pswap=0.1)

@@ -1408,3 +1408,44 @@ def test_trans_dimensional_changepoint_many_chains_vs_oracle(ra, orc, KM, N):
     np.testing.assert_allclose(s._chain_logpost, hl, rtol=RTOL)
     assert set(np.unique(mv)) >= {0, 1, 2, 3, 4} and (mv == 5).any()
     assert (acc[mv == 3] == 1).sum() > 20 and (acc[mv == 4] == 1).sum() > 20
+
+
+def test_parallel_tempering_with_hmc_within_the_rungs(ra, orc):
+    """PTSampler + VanillaHMC / MALA: reference fixture, then many ladders on a 100-d Gaussian
+    and on the logistic model against the oracle.  The trajectories use the base model's
+    gradient on every rung (the reference hands all rungs one proposal), the accept test the
+    tempered posterior; an accepted swap exchanges states AND cached gradients."""
+    from riemann_amd.models import LogisticRegression, MultiGaussianDist
+    from riemann_amd.proposals import MALA, VanillaHMC
+    from riemann_amd.samplers import PTSampler
+    from riemann_amd.workloads import logreg_data
+    z = load("g12_pt_hmc_gauss2d")
+    m = MultiGaussianDist(z["mu"], z["C"])
+    pt = PTSampler(m, VanillaHMC(float(z["eps"]), int(z["nsteps"]), m), z["theta0"], Pswap=float(z["pswap"]),
+                   seed=int(z["seed"]))
+    pt.run(50)
+    pt.run(46)
+    check_pt(z, pt)
+    g = np.random.default_rng(8)
+    d = 100
+    A = g.standard_normal((d, d))
+    Cm = A @ A.T / d + 0.5 * np.eye(d)
+    X, y = logreg_data(300, 24, seed=5)
+    cases = [(MultiGaussianDist(np.zeros(d), Cm), orc.Gaussian(np.zeros(d), Cm), d, 0.25, 3, 5),
+             (LogisticRegression(X, y, 100.0), orc.LogReg(X, y, 100.0), 24, 0.4, 1, 4)]
+    for m, om, dd, eps, L, K in cases:
+        Ne, T = 200, 16
+        betas = 0.7 ** np.arange(K)
+        th0 = 0.3 * g.standard_normal((Ne, dd))
+        prop = MALA(eps, m) if L == 1 else VanillaHMC(eps, L, m)
+        pt = PTSampler(m, prop, th0, betas=betas, Pswap=0.3, seed=11)
+        pt.run(T)
+        S, idx = orc.pt_slots(Ne, K)
+        slots = np.zeros((S, dd))
+        slots[:] = th0[0]
+        slots[idx] = th0[:, None, :]
+        ht, hl, code, _ = orc.run_pt(om, orc.HMC(eps, L, dd), slots, orc.rng_seed(11, S), T, betas, 0.3)
+        np.testing.assert_array_equal(pt._host_codes, code[:, idx])
+        np.testing.assert_allclose(pt._host_thetas, ht[:, idx], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(pt._host_logpost, hl[:, idx], rtol=1e-8)
+        assert (code[:, idx] == 3).sum() > 20 and (code[:, idx] == 1).sum() > 100

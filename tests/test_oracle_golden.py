@@ -296,7 +296,7 @@ def test_g11_mixture_values_and_random_walk():
     check_run(z, *replay(z, orc.Mixture(MIX1D), orc.RandomWalk(z["Cprop"])))
 
 
-def pt_replay(z, model):
+def pt_replay(z, model, prop=None):
     """The oracle's PT run on the fixture's slot layout: (hist_theta, hist_logpost, code)."""
     idx = z["slots"]
     Ne, K = idx.shape
@@ -306,7 +306,8 @@ def pt_replay(z, model):
     th[idx] = z["theta0"][:, None, :]            # PTSampler gives every rung the same theta0 (:82)
     st = orc.rng_seed(int(z["seed"]), S)
     T = z["swap_prop"].shape[0]
-    ht, hl, code, _ = orc.run_pt(model, orc.RandomWalk(z["Cprop"]), th, st, T, z["betas"], float(z["pswap"]))
+    prop = prop or orc.RandomWalk(z["Cprop"])
+    ht, hl, code, _ = orc.run_pt(model, prop, th, st, T, z["betas"], float(z["pswap"]))
     return ht, hl, code, idx.ravel()
 
 
@@ -326,6 +327,8 @@ def test_g12_parallel_tempering():
     check_pt(z, *pt_replay(z, orc.Gaussian(z["mu"], z["C"])))
     z = load("g12_pt_mix2d")
     check_pt(z, *pt_replay(z, orc.Mixture(MIX2D)))
+    z = load("g12_pt_hmc_gauss2d")       # HMC within the rungs, base-model gradient
+    check_pt(z, *pt_replay(z, orc.Gaussian(z["mu"], z["C"]), orc.HMC(float(z["eps"]), int(z["nsteps"]), 2)))
 
 
 def test_g13_changepoint_block_proposal():

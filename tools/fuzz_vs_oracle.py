@@ -136,7 +136,11 @@ def one(g, it):
         betas = np.sort(g.uniform(0.0, 1.0, size=K))[::-1].copy()
         pswap = float(g.uniform(0.05, 0.9))
         chain0 = 16 * int(g.integers(0, 1000))
-        pt = PTSampler(m, P.MetropolisRandomWalk(Cp), th0, betas=betas, Pswap=pswap, seed=seed, chain0=chain0)
+        hmc = kind in ("gauss", "logreg") and g.uniform() < 0.4
+        Lh = int(g.integers(1, 4))
+        wprop = P.VanillaHMC(0.2, Lh, m) if hmc else P.MetropolisRandomWalk(Cp)
+        oprop = orc.HMC(0.2, Lh, d) if hmc else orc.RandomWalk(Cp)
+        pt = PTSampler(m, wprop, th0, betas=betas, Pswap=pswap, seed=seed, chain0=chain0)
         T1 = int(g.integers(0, T + 1))
         pt.run(T1)                       # histories append across run() calls
         pt.run(T - T1)
@@ -144,8 +148,8 @@ def one(g, it):
         slots = np.zeros((S, d))
         slots[:] = th0[0]
         slots[idx] = th0[:, None, :]
-        ht, hl, code, _ = orc.run_pt(om, orc.RandomWalk(Cp), slots, orc.rng_seed(seed, S, chain0=chain0), T, betas, pswap)
-        desc += " K=%d T1=%d" % (K, T1)
+        ht, hl, code, _ = orc.run_pt(om, oprop, slots, orc.rng_seed(seed, S, chain0=chain0), T, betas, pswap)
+        desc += " K=%d T1=%d%s" % (K, T1, " hmc" if hmc else "")
         assert np.array_equal(pt._host_codes, code[:, idx]), desc + " codes"
         np.testing.assert_allclose(pt._host_thetas, ht[:, idx], rtol=1e-8, atol=1e-11, err_msg=desc)
         ref = hl[:, idx]

@@ -71,7 +71,8 @@ int rmh_model_changepoint_create(const double *x, const double *y, int n, int k,
 /* benchmarks.MixtureDist(components) with MultiGaussianDist components,
  * models/benchmarks.py:31-62 (targets benchmark_gauss1d_mix2, benchmark_gauss2d_mix2_cross,
  * :75-85).  weights (ncomp) NORMALISED as at :40, mu (ncomp,d), L (ncomp,d,d) the components'
- * Cholesky factors, log_prior the constant log(sum(w exp(0))) of :54-62.  No gradient. */
+ * Cholesky factors, log_prior the constant log(sum(w exp(0))) of :54-62.  The gradient
+ * (rmh_grad_log_posterior, HMC proposals) is an addition: the reference class has none. */
 int rmh_model_mixture_create(const double *weights, const double *mu, const double *L, int ncomp,
                              int d, double log_prior, rmh_model_t *out);
 /* ChangepointRegression1D with a VARIABLE number of changepoints k <= kmax (the model's own

@@ -462,6 +462,22 @@ static void orc_grad1(const orc_model *m, const double *th, double *g, double *s
         for (int j = 0; j < d; j++) g[j] -= th[j] / m->tau2;
         break;
     }
+    case ORC_MIXTURE: { /* d/dtheta log sum_k w_k N_k = sum_k w_k N_k grad(log N_k) / sum_k w_k N_k;
+                         * NOT in the reference (benchmarks.MixtureDist has no gradient): the build's
+                         * plugin addition, like the logistic model */
+        double den = 0;
+        double *gk = (double *)malloc(sizeof(double) * 2 * d), *sk = gk + d;
+        for (int j = 0; j < d; j++) g[j] = 0;
+        for (int k = 0; k < m->ncomp; k++) {
+            const double e = m->wts[k] * exp(orc_log_lik1(m->comps[k], th, sk));
+            orc_grad1(m->comps[k], th, gk, sk);
+            for (int j = 0; j < d; j++) g[j] += e * gk[j];
+            den += e;
+        }
+        for (int j = 0; j < d; j++) g[j] /= den;
+        free(gk);
+        break;
+    }
     default:
         for (int j = 0; j < d; j++) g[j] = NAN; /* no gradient (changepoint.py:108-113) */
     }

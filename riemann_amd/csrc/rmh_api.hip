@@ -148,9 +148,7 @@ int eval_states(rmh_model *m, const ChainArgs &c, bool want_grad, double *lp, do
         e = launch_cprj_eval(m->rj, c, lprior, llik, lp, g_stream);
         break;
     case kMixture:
-        if (want_grad)
-            return fail(RMH_ERR_PARAM, "MixtureDist has no gradient (riemann/models/benchmarks.py:31-62)");
-        e = launch_mix_eval(m->NT, m->ma, c, lp, lprior, llik, g_stream);
+        e = launch_mix_eval(m->NT, m->ma, c, want_grad, lp, grad, lprior, llik, g_stream);
         break;
     case kChangepoint:
         if (want_grad)
@@ -391,7 +389,7 @@ int rmh_model_mixture_create(const double *weights, const double *mu, const doub
     if (!weights || !mu || !L || !out || ncomp < 1 || d < 1) return fail(RMH_ERR_PARAM, "mixture: bad argument");
     const int NT = nt_for_dim(d);
     if (NT < 0) return fail(RMH_ERR_PARAM, "mixture: d > 112 is not supported by the MFMA tile yet");
-    std::vector<double> imgs, mus((size_t)ncomp * 16 * NT, 0.0), cst(ncomp);
+    std::vector<double> imgs, imgsT, mus((size_t)ncomp * 16 * NT, 0.0), cst(ncomp);
     for (int k = 0; k < ncomp; ++k) {
         const double *Lk = L + (size_t)k * d * d;
         if (!lower_ok(Lk, d))
@@ -403,8 +401,9 @@ int rmh_model_mixture_create(const double *weights, const double *mu, const doub
                 for (int j = col; j < i; ++j) acc -= Lk[i * d + j] * W[j * d + col];
                 W[i * d + col] = acc / Lk[i * d + i];
             }
-        std::vector<double> lo = pack_lower(W.data(), d, NT, 1.0);
+        std::vector<double> lo = pack_lower(W.data(), d, NT, 1.0), up = pack_upper_T(W.data(), d, NT);
         imgs.insert(imgs.end(), lo.begin(), lo.end());
+        imgsT.insert(imgsT.end(), up.begin(), up.end());
         for (int i = 0; i < d; ++i) mus[(size_t)k * 16 * NT + i] = mu[(size_t)k * d + i];
         double slog = 0.0;
         for (int i = 0; i < d; ++i) slog += std::log(Lk[i * d + i]);
@@ -416,6 +415,7 @@ int rmh_model_mixture_create(const double *weights, const double *mu, const doub
     m->NT = NT;
     int rc;
     if ((rc = upload(&m->d_mixW, imgs.data(), imgs.size())) ||
+        (rc = upload(&m->d_mixWT, imgsT.data(), imgsT.size())) ||
         (rc = upload(&m->d_mixmu, mus.data(), mus.size())) ||
         (rc = upload(&m->d_mixc, cst.data(), cst.size())) ||
         (rc = upload(&m->d_mixw, weights, (size_t)ncomp))) {
@@ -423,6 +423,7 @@ int rmh_model_mixture_create(const double *weights, const double *mu, const doub
         return rc;
     }
     m->ma.Wtiles = m->d_mixW;
+    m->ma.WTtiles = m->d_mixWT;
     m->ma.mu_pad = m->d_mixmu;
     m->ma.cst = m->d_mixc;
     m->ma.wts = m->d_mixw;
@@ -578,6 +579,7 @@ int rmh_model_free(rmh_model_t m)
     (void)hipFree(m->d_xy);
     (void)hipFree(m->d_ktab);
     (void)hipFree(m->d_mixW);
+    (void)hipFree(m->d_mixWT);
     (void)hipFree(m->d_mixmu);
     (void)hipFree(m->d_mixc);
     (void)hipFree(m->d_mixw);
@@ -860,6 +862,7 @@ int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
             HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT, p->minv};
             if (rc) {} else if (m->kind == kGauss) e = launch_gauss_propose_hmc(m->NT, m->ga, ha, c, outp, lq, g_stream);
             else if (m->kind == kLogReg) e = launch_logreg_propose_hmc(m->NT, m->la, ha, c, outp, lq, g_stream);
+            else if (m->kind == kMixture) e = launch_mix_propose_hmc(m->NT, m->ma, ha, c, outp, lq, g_stream);
             else rc = fail(RMH_ERR_PARAM, "hmc: this model has no gradient");
         }
     }

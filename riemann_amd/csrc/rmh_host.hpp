@@ -31,6 +31,7 @@ struct rmh_model {
     double *d_ktab = nullptr;
     rmh::CpRjArgs rj{};
     // mixture of gaussians
+    double *d_mixWT = nullptr;
     double *d_mixW = nullptr, *d_mixmu = nullptr, *d_mixc = nullptr, *d_mixw = nullptr;
     rmh::MixArgs ma{};
 };

@@ -22,6 +22,7 @@ struct GaussArgs {
 // benchmarks.MixtureDist of MultiGaussianDist components (models/benchmarks.py:31-62)
 struct MixArgs {
     const double *Wtiles;  // ncomp lower-triangular tile images of W_k = L_k^-1 (global memory, L2)
+    const double *WTtiles; // ncomp upper-triangular tile images of W_k^T (gradient)
     const double *mu_pad;  // ncomp x 16*NT doubles
     const double *cst;     // ncomp: logdetC_k
     const double *wts;     // ncomp normalised weights
@@ -133,8 +134,12 @@ hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const Ch
                            const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_gauss_pt(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                            const RunArgs &r, hipStream_t st);
-hipError_t launch_mix_eval(int NT, const MixArgs &m, const ChainArgs &c, double *lp_out,
-                           double *lprior_out, double *llik_out, hipStream_t st);
+hipError_t launch_mix_eval(int NT, const MixArgs &m, const ChainArgs &c, int want_grad, double *lp_out,
+                           double *grad_out, double *lprior_out, double *llik_out, hipStream_t st);
+hipError_t launch_mix_hmc(int NT, const MixArgs &m, const HmcArgs &p, const ChainArgs &c,
+                          const RunArgs &r, bool adapt, hipStream_t st);
+hipError_t launch_mix_propose_hmc(int NT, const MixArgs &m, const HmcArgs &p, const ChainArgs &c,
+                                  double *theta_p, double *logq, hipStream_t st);
 // r.pt_K > 0 selects the parallel-tempering variant
 hipError_t launch_mix_rw(int NT, const MixArgs &m, const RwArgs &p, const ChainArgs &c,
                          const RunArgs &r, bool adapt, hipStream_t st);

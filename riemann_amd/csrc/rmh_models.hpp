@@ -116,13 +116,19 @@ struct MixModel {
     static constexpr __host__ __device__ size_t lds_doubles(bool) { return 0; }
     static RMH_DEV void setup(double *, const Args &, bool) {}
 
+    // GRAD: d/dtheta log sum_k w_k N_k = sum_k e_k g_k / sum_k e_k with e_k = w_k exp(logL_k) and
+    // g_k = -W_k^T W_k (theta - mu_k) (gaussian.py:54-58).  The reference's MixtureDist has no
+    // gradient; this is the build's addition so that MALA / HMC can run on the mixture targets.
     template <bool GRAD, bool VALUE = true>
     static RMH_DEV void eval(const double *, const Args &m, bool, int lane, const double (&th)[S],
                              double &lp, double (&grad)[S], double (&parts)[2])
     {
-        static_assert(!GRAD, "MixtureDist has no gradient");
         const int g = lane >> 4;
         double acc = 0.0;
+        if (GRAD) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) grad[s] = 0.0;
+        }
         for (int k = 0; k < m.ncomp; ++k) {
             asm volatile("" ::: "memory");
             const double *W = m.Wtiles + (size_t)k * kImg + lane;
@@ -140,13 +146,29 @@ struct MixModel {
                 uu += a[i].x * a[i].x + a[i].y * a[i].y + a[i].z * a[i].z + a[i].w * a[i].w;
             uu = sum4(uu);
             const double logLk = -0.5 * ((uu + m.dlog2pi) + m.cst[k]); // gaussian.py:49-52
-            acc += m.wts[k] * exp(logLk);
+            const double ek = m.wts[k] * exp(logLk);
+            acc += ek;
+            if (GRAD) {
+                double u[S];
+                T::unpack(a, u);
+                double4_t v[NT];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) v[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+                T::template mul_upper<true>(m.WTtiles + (size_t)k * kImg + lane, u, v, m.ks);
+                double gk[S];
+                T::unpack(v, gk);
+#pragma unroll
+                for (int s = 0; s < S; ++s) grad[s] = grad[s] + ek * (-gk[s]);
+            }
+        }
+        if (GRAD) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) grad[s] = grad[s] / acc;
         }
         const double logL = log_full(acc);
         lp = combine_post(m.logP0, logL);
         parts[0] = m.logP0;
         parts[1] = logL;
-        (void)grad;
     }
 };
 

@@ -241,8 +241,9 @@ static int run_adaptcov(rmh_model *m, rmh_proposal *p, rmh_state *s, const Chain
         r.h_accept = s->sc_accept;
         if (p->kind == kHMC) {
             HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT, p->minv};
-            RMH_HIP(m->kind == kGauss ? launch_gauss_hmc(m->NT, m->ga, ha, c, r, false, g_stream)
-                                      : launch_logreg_hmc(m->NT, m->la, ha, c, r, false, g_stream));
+            RMH_HIP(m->kind == kGauss     ? launch_gauss_hmc(m->NT, m->ga, ha, c, r, false, g_stream)
+                    : m->kind == kMixture ? launch_mix_hmc(m->NT, m->ma, ha, c, r, false, g_stream)
+                                          : launch_logreg_hmc(m->NT, m->la, ha, c, r, false, g_stream));
         } else {
             RMH_HIP(launch_rw_plain(m, p, c, r, c.adapt != nullptr));
         }
@@ -346,7 +347,7 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         e = launch_big_gauss_rw(m->NT, m->ga, ra, c, r, g_stream);
     } else if (p->acov) {
         if (K > 0 || p->kind == kPCN || p->nblk > 0 ||
-            (p->kind == kHMC && (adapt || m->kind == kMixture || m->kind == kChangepoint)))
+            (p->kind == kHMC && (adapt || m->kind == kChangepoint)))
             return fail(RMH_ERR_PARAM, "run: AdaptCov is built for the random walk (plain or with scale "
                                        "adaptation) and for HMC on the Gaussian, mixture (random walk) "
                                        "and logistic models");
@@ -387,7 +388,8 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         else e = launch_logreg_rw(m->NT, m->la, ra, c, r, adapt, g_stream);
     } else {
         HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT, p->minv};
-        if (m->kind == kMixture) return fail(RMH_ERR_PARAM, "hmc: MixtureDist has no gradient");
+        if (m->kind == kMixture) e = launch_mix_hmc(m->NT, m->ma, ha, c, r, adapt, g_stream);
+        else
         if (m->kind == kGauss) e = launch_gauss_hmc(m->NT, m->ga, ha, c, r, adapt, g_stream);
         else e = launch_logreg_hmc(m->NT, m->la, ha, c, r, adapt, g_stream);
     }

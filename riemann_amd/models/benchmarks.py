@@ -16,7 +16,8 @@ class MixtureDist(DeviceModel):
     ``components``: list of ``(weight, dist)`` as in the reference.  The device kernel
     is built for MultiGaussianDist components of one dimension; densities follow the
     reference operation for operation (no log-sum-exp: far from every component the
-    likelihood underflows to ``-inf``)."""
+    likelihood underflows to ``-inf``).  ``grad_log_posterior`` is an addition (the reference's
+    class has no gradient): it lets MALA / HMC proposals run on mixture targets."""
 
     def __init__(self, components):
         weights, models = zip(*components)

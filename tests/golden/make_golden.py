@@ -433,6 +433,16 @@ def g11_mixture():
     th0 = rng.standard_normal((4, 2))
     r = run_reference(m, lambda: MetropolisRandomWalk(1.5 * np.eye(2)), th0, seed=110, T=96)
     save("g11_mixture_rw", Cprop=1.5 * np.eye(2), **r)
+    # HMC / MALA on the mixture: the reference's MixtureDist has no gradient, so the callable the
+    # reference's VanillaHMC is given here is the build's own statement of it (as for the logistic
+    # plugin): grad log sum_k w_k N_k = sum_k w_k N_k grad(log N_k) / sum_k w_k N_k
+    def mix_grad(th):
+        e = np.array([w * np.exp(c.log_likelihood(th)) for w, c in zip(m._mixweights, m._model_list)])
+        gk = np.array([c.grad_log_likelihood(th) for c in m._model_list])
+        return (e[:, None] * gk).sum(axis=0) / e.sum()
+    for tag, eps, L in (("mala", 0.5, 1), ("hmc4", 0.3, 4)):
+        r = run_reference(m, lambda: VanillaHMC(eps, L, mix_grad), th0, seed=112 + L, T=64)
+        save("g11_mixture_" + tag, eps=np.float64(eps), nsteps=np.int64(L), **r)
     m1 = rbench.benchmark_gauss1d_mix2
     r = run_reference(m1, lambda: MetropolisRandomWalk(np.array([[9.0]])), np.array([[5.0], [-5.0], [0.0], [1.0]]),
                       seed=111, T=96)

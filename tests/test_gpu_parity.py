@@ -705,8 +705,19 @@ def test_g11_mixture_values_and_random_walk(ra):
                    seed=int(z["seed"]))
     s.run(96)
     check_run(z, s)
-    with pytest.raises(ra.ParameterError):
-        b.benchmark_gauss2d_mix2_cross.grad_log_posterior(np.zeros(2))
+    # gradient (the build's addition) and HMC / MALA on the mixture
+    from oracle import oracle as orc
+    from riemann_amd.proposals import MALA, VanillaHMC
+    mx = b.benchmark_gauss2d_mix2_cross
+    pts = np.random.default_rng(0).standard_normal((50, 2)) * 2.0
+    np.testing.assert_allclose(mx.grad_log_posterior(pts), orc.Mixture(MIX2D).grad_log_posterior(pts), rtol=1e-9)
+    for tag in ("mala", "hmc4"):
+        z = load("g11_mixture_" + tag)
+        L = int(z["nsteps"])
+        prop = MALA(float(z["eps"]), mx) if L == 1 else VanillaHMC(float(z["eps"]), L, mx)
+        s = ra.Sampler(mx, prop, z["theta0"], seed=int(z["seed"]))
+        s.run(64)
+        check_run(z, s)
 
 
 def check_pt(z, pt):

@@ -294,6 +294,9 @@ def test_g11_mixture_values_and_random_walk():
     check_run(z, *replay(z, orc.Mixture(MIX2D), orc.RandomWalk(z["Cprop"])))
     z = load("g11_mixture1d_rw")
     check_run(z, *replay(z, orc.Mixture(MIX1D), orc.RandomWalk(z["Cprop"])))
+    for tag in ("mala", "hmc4"):          # the build's mixture gradient inside the reference's VanillaHMC
+        z = load("g11_mixture_" + tag)
+        check_run(z, *replay(z, orc.Mixture(MIX2D), orc.HMC(float(z["eps"]), int(z["nsteps"]), 2)))
 
 
 def pt_replay(z, model, prop=None):

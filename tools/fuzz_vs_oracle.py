@@ -112,12 +112,12 @@ def one(g, it):
         assert np.array_equal(np.isfinite(a), np.isfinite(b)), "%s %s d=%d finite" % (kind, fn, d)
         fin = np.isfinite(b)
         np.testing.assert_allclose(a[fin], b[fin], rtol=1e-8, atol=1e-10, err_msg="%s %s d=%d" % (kind, fn, d))
-    if kind in ("gauss", "logreg"):
+    if kind in ("gauss", "logreg", "mix"):
         np.testing.assert_allclose(m.grad_log_posterior(th0), om.grad_log_posterior(th0), rtol=1e-7, atol=1e-9,
                                    err_msg="%s grad d=%d" % (kind, d))
     Cp = (0.5 / d) * spd(g, d)
     props = ["rw", "arw", "pcn", "apcn", "acov", "pt"]
-    if kind in ("gauss", "logreg"):
+    if kind in ("gauss", "logreg", "mix"):
         props += ["hmc", "mala", "hmcm", "ahmc", "acovhmc"]
     if kind != "bigd":
         props += ["asc"]

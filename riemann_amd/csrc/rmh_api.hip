@@ -65,6 +65,18 @@ std::vector<double> pack_upper_T(const double *M, int d, int NT)
     return img;
 }
 
+std::vector<double> pack_tail(const double *M, int d, double scale)
+{
+    std::vector<double> t((size_t)25 * 16, 0.0);
+    for (int s = 0; s < 25; ++s)
+        for (int g = 0; g < 4; ++g)
+            for (int r = 0; r < 4; ++r) {
+                const int row = 96 + r, col = 4 * s + g;
+                if (row < d && col < d && col <= row) t[(size_t)(s * 4 + g) * 4 + r] = scale * M[(size_t)row * d + col];
+            }
+    return t;
+}
+
 bool lower_ok(const double *L, int d)
 {
     for (int i = 0; i < d; ++i) {
@@ -120,6 +132,14 @@ int sync_proposal(rmh_proposal *p)
         if (rc) return rc;
     }
     RMH_HIP(hipMemcpy(p->d_Ltiles, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (p->kind == kRW && has_tail(p->d)) { // rows 96.. for the VALU tail of k_run_rw_tail
+        std::vector<double> lt = pack_tail(p->L.data(), p->d, sc);
+        if (!p->d_Ltail) {
+            int rc = dev_alloc(&p->d_Ltail, lt.size());
+            if (rc) return rc;
+        }
+        RMH_HIP(hipMemcpy(p->d_Ltail, lt.data(), lt.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     p->dirty = false;
     return RMH_OK;
 }
@@ -372,6 +392,14 @@ int rmh_model_gaussian_create(const double *mu, const double *L, int d, rmh_mode
         rmh_model_free(m);
         return rc;
     }
+    if (has_tail(d)) {
+        std::vector<double> wt = pack_tail(W.data(), d, 1.0);
+        if ((rc = upload(&m->d_Wtail, wt.data(), wt.size()))) {
+            rmh_model_free(m);
+            return rc;
+        }
+    }
+    m->ga.Wtail = m->d_Wtail;
     m->ga.Wtiles = m->d_W;
     m->ga.WTtiles = m->d_WT;
     m->ga.mu_pad = m->d_mu;
@@ -575,6 +603,7 @@ int rmh_model_free(rmh_model_t m)
     (void)hipFree(m->d_W);
     (void)hipFree(m->d_WT);
     (void)hipFree(m->d_mu);
+    (void)hipFree(m->d_Wtail);
     (void)hipFree(m->d_X);
     (void)hipFree(m->d_xy);
     (void)hipFree(m->d_ktab);
@@ -795,6 +824,7 @@ int rmh_proposal_free(rmh_proposal_t p)
 {
     if (!p) return RMH_OK;
     (void)hipFree(p->d_Ltiles);
+    (void)hipFree(p->d_Ltail);
     (void)hipFree(p->d_chM);
     (void)hipFree(p->d_V);
     (void)hipFree(p->d_VT);

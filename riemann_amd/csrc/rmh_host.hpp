@@ -18,7 +18,7 @@ struct rmh_model {
     int kind = 0, d = 0, NT = 0;
     bool big = false; // 112 < d <= 896: rmh_kernels_big.hip (Gaussian, value only)
     // gaussian
-    double *d_W = nullptr, *d_WT = nullptr, *d_mu = nullptr;
+    double *d_W = nullptr, *d_WT = nullptr, *d_mu = nullptr, *d_Wtail = nullptr;
     rmh::GaussArgs ga{};
     // logreg
     double *d_X = nullptr;
@@ -42,6 +42,7 @@ struct rmh_proposal {
     int nsteps = 0;
     std::vector<double> L;     // host copy of the Cholesky factor
     double *d_Ltiles = nullptr;
+    double *d_Ltail = nullptr;  // rows 96.. of scale*L for k_run_rw_tail (d = 97..100), or null
     bool dirty = true;
     double *d_chM = nullptr, *d_V = nullptr, *d_VT = nullptr; // mass-matrix tile images (HMC)
     double minv = 1.0;                                        // M^-1 = minv (chM chM^T)^-1
@@ -137,6 +138,9 @@ int64_t pad16(int64_t n);
 std::vector<double> pack_lower(const double *M, int d, int NT, double scale);
 std::vector<double> pack_upper_T(const double *M, int d, int NT);
 bool lower_ok(const double *L, int d);
+// rows 96..99 of a lower-triangular (d, d) matrix, [s][g][r] = scale * M[96 + r][4s + g] (25 x 4 x 4)
+std::vector<double> pack_tail(const double *M, int d, double scale);
+inline bool has_tail(int d) { return d >= 97 && d <= 100; }
 bool cholesky_lower(const std::vector<double> &Cm, int d, std::vector<double> &L);
 
 ChainArgs chain_args(const rmh_state *s);

@@ -17,6 +17,9 @@ struct GaussArgs {
     double dlog2pi;        // d*log(2 pi)
     double logdetC;
     int ks;                // ceil(d/4): k-steps that carry data
+    // rows 96.. of W when the last 16-row tile holds at most 4 rows (d = 97..100), laid out
+    // [s][g][r] = W[96 + r][4s + g]: see k_run_rw_tail (rmh_run.hpp); null otherwise
+    const double *Wtail;
 };
 
 // benchmarks.MixtureDist of MultiGaussianDist components (models/benchmarks.py:31-62)
@@ -97,6 +100,7 @@ struct RwArgs {
     const double *Ltiles; // lower-triangular tile image of scale*L (rho_c*L for pCN), staged in LDS
     const double *Vtiles; // pCN: tile image of (rho_c*L)^-1, read from global memory (L2)
     double rho;           // pCN (proposals/randomwalk.py:83-86)
+    const double *Ltail;  // rows 96.. of scale*L in the layout of GaussArgs::Wtail, or null
     // block-mixture random walk (ChangepointRegression1DProp, riemann/test_changepoint.py:18-56):
     // nblk <= 3 consecutive coordinate blocks ending at blk_end[b], picked by chained
     // uniforms against blk_p[b]; nblk = 0: plain full-vector random walk
@@ -132,6 +136,8 @@ hipError_t launch_gauss_eval(int NT, const GaussArgs &m, const ChainArgs &c, int
 // `adapt`: run the AdaptScale* variant (c.adapt / c.adapt_target set, tile image unscaled)
 hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                            const RunArgs &r, bool adapt, hipStream_t st);
+hipError_t launch_gauss_rw_tail(const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
+                                const RunArgs &r, hipStream_t st);
 hipError_t launch_gauss_pt(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                            const RunArgs &r, hipStream_t st);
 hipError_t launch_mix_eval(int NT, const MixArgs &m, const ChainArgs &c, int want_grad, double *lp_out,

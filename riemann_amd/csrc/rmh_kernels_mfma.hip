@@ -61,6 +61,14 @@ hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const Ch
     })
 }
 
+// d = 97..100, plain random walk: rows 96..99 on the VALU (k_run_rw_tail)
+hipError_t launch_gauss_rw_tail(const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
+                                const RunArgs &r, hipStream_t st)
+{
+    const size_t lds = sizeof(double) * (2 * tri_tiles(6) * 64 + 2 * kTailDoubles + 4 * 28 + kIcdfDoubles);
+    return launch(k_run_rw_tail<8>, c.nblocks, 8, lds, st, m, p, c, r);
+}
+
 // parallel tempering over a Gaussian target: one wave per SIMD (register budget)
 hipError_t launch_gauss_pt(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                            const RunArgs &r, hipStream_t st)

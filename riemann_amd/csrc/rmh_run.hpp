@@ -263,6 +263,141 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
     }
 }
 
+// -------------------------------------- random walk, d = 97..100 (BASELINE cfg 2) --
+// With 16-row tiles a 100-dimensional triangular product spends 25 of its 109 MFMAs on the
+// seventh row tile, which holds 4 real rows.  v_mfma_f64 and the VALU share the FP64 units on
+// this chip (rmh_run.hpp header), so those 4 rows are cheaper as plain FMAs: every lane forms
+// the partial dot products of rows 96..99 over its own 25 coordinates (row coefficients from
+// LDS, [s][g][r] so that one ds_read_b128 pair serves four FMAs), the chain's four lanes add
+// them up, and lane group g keeps row 96+g -- exactly the register the MFMA would have written
+// (tile 6, register 0).  1600 MFMA cycles become ~540 VALU cycles per product.
+// Plain MetropolisRandomWalk on MultiGaussianDist only; same results as k_run_rw up to the
+// summation order inside those four rows.
+constexpr int kTailS = 25, kTailDoubles = kTailS * 16;
+
+RMH_DEV double tail_rows(const double *lt, int g, const double (&v)[28])
+{
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const d2_t *p = static_cast<const d2_t *>(__builtin_assume_aligned(lt + g * 4, 16));
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+    for (int s = 0; s < kTailS; ++s) {
+        const d2_t a = p[s * 8], b = p[s * 8 + 1]; // [s][g][0..1], [s][g][2..3]
+        t0 = fma_(a.x, v[s], t0);
+        t1 = fma_(a.y, v[s], t1);
+        t2 = fma_(b.x, v[s], t2);
+        t3 = fma_(b.y, v[s], t3);
+    }
+    t0 = sum4(t0);
+    t1 = sum4(t1);
+    t2 = sum4(t2);
+    t3 = sum4(t3);
+    return g == 0 ? t0 : g == 1 ? t1 : g == 2 ? t2 : t3;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
+{
+    constexpr int NT = 7, S = 28, NF = 6, kFull = tri_tiles(NF) * 64; // six full row tiles: 84 tile images
+    using T = Tile<NT>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *Limg = lds, *Wimg = lds + kFull;
+    double *Lt = Wimg + kFull, *Wt = Lt + kTailDoubles;
+    double *mu = Wt + kTailDoubles;
+    double *tab = mu + 4 * S;
+    for (int i = threadIdx.x; i < kFull; i += blockDim.x) {
+        Limg[i] = pr.Ltiles[i];
+        Wimg[i] = m.Wtiles[i];
+    }
+    for (int i = threadIdx.x; i < kTailDoubles; i += blockDim.x) {
+        Lt[i] = pr.Ltail[i];
+        Wt[i] = m.Wtail[i];
+    }
+    for (int i = threadIdx.x; i < 4 * S; i += blockDim.x) mu[i] = m.mu_pad[i];
+    icdf_stage(tab, ch.icdf);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, g = lane >> 4;
+    int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const bool active = blk < ch.nblocks;
+    if (!active) blk = ch.nblocks - 1;
+    const int64_t c = blk * 16 + cl;
+    const int64_t slot = blk * 64 + lane;
+
+    double th[S];
+    T::load_state(ch.theta, ch.ld, c, g, th);
+    double lp = ch.logpost[c];
+    Xo rng = xo_load(ch.rng, ch.nslots, slot);
+    Keep keep(run);
+    keep.record<NT>(run, ch, 0, c, g, active, th, lp);
+
+    for (int64_t t = 0; t < run.T; ++t) {
+        asm volatile("" ::: "memory");
+        double xi[S];
+        T::normals(rng, ch.M, ch.d, g, tab, xi);
+        // theta' = theta + scale * L xi: row tiles 0..5 on the matrix core, rows 96..99 on the VALU
+        double4_t acc[NF];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            acc[i].x = th[4 * i + 0];
+            acc[i].y = th[4 * i + 1];
+            acc[i].z = th[4 * i + 2];
+            acc[i].w = th[4 * i + 3];
+        }
+#pragma unroll
+        for (int s = 0; s < 4 * NF; ++s) {
+#pragma unroll
+            for (int i = s / 4; i < NF; ++i) acc[i] = mfma(Limg[T::lo(i, s) * 64 + lane], xi[s], acc[i]);
+        }
+        double thp[S];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            thp[4 * i + 0] = acc[i].x;
+            thp[4 * i + 1] = acc[i].y;
+            thp[4 * i + 2] = acc[i].z;
+            thp[4 * i + 3] = acc[i].w;
+        }
+        thp[24] = th[24] + tail_rows(Lt, g, xi);
+        thp[25] = th[25];
+        thp[26] = th[26];
+        thp[27] = th[27];
+        // log posterior: |W (theta' - mu)|^2, two row tiles in flight, then the four tail rows
+        double y[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) y[s] = thp[s] - mu[4 * s + g];
+        double uu = 0.0;
+#pragma unroll
+        for (int i0 = 0; i0 < NF; i0 += 2) {
+            double4_t a0 = double4_t{0.0, 0.0, 0.0, 0.0}, a1 = a0;
+#pragma unroll
+            for (int s = 0; s < 4 * (i0 + 2); ++s) {
+                if (s < 4 * (i0 + 1)) a0 = mfma(Wimg[T::lo(i0, s) * 64 + lane], y[s], a0);
+                a1 = mfma(Wimg[T::lo(i0 + 1, s) * 64 + lane], y[s], a1);
+            }
+            uu += a0.x * a0.x + a0.y * a0.y + a0.z * a0.z + a0.w * a0.w;
+            uu += a1.x * a1.x + a1.y * a1.y + a1.z * a1.z + a1.w * a1.w;
+        }
+        const double ut = tail_rows(Wt, g, y);
+        uu += ut * ut;
+        uu = sum4(uu);
+        const double logL = -0.5 * ((uu + m.dlog2pi) + m.logdetC);
+        const double lpp = combine_post(0.0, logL);
+        const double u = T::accept_uniform(rng, g, cl);
+        const bool acc_ok = mh_accept(lpp, lp, 0.0, u);
+#pragma unroll
+        for (int s = 0; s < S; ++s) th[s] = acc_ok ? thp[s] : th[s];
+        lp = acc_ok ? lpp : lp;
+        if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = acc_ok ? 1 : 0;
+        keep.record<NT>(run, ch, t + 1, c, g, active, th, lp);
+    }
+    if (active) {
+        T::store_state(ch.theta, ch.ld, c, g, th);
+        if (g == 0) ch.logpost[c] = lp;
+        xo_store(ch.rng, ch.nslots, slot, rng);
+    }
+}
+
 // ------------------------------------------------------------ HMC / MALA ----
 // VanillaHMC.propose + leapfrog with M = None.  The gradient at the current
 // state is cached in ch.grad (same point, same function => same bits as the

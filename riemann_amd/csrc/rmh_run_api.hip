@@ -4,6 +4,8 @@
 // the C ABI and rmh_host.hpp for the shared handle types.
 #include "rmh_host.hpp"
 
+#include <cstdlib>
+
 using namespace rmh;
 using namespace rmh::host;
 
@@ -381,7 +383,10 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
                 ra.blk_p[b] = p->blk_p[b];
             }
         }
-        if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
+        if (m->kind == kGauss && !adapt && m->ga.Wtail && p->d_Ltail && !getenv("RMH_NO_TAIL")) {
+            ra.Ltail = p->d_Ltail;   // d = 97..100: rows 96..99 on the VALU instead of a 7th row tile
+            e = launch_gauss_rw_tail(m->ga, ra, c, r, g_stream);
+        } else if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
         else if (m->kind == kChangepoint && adapt) e = launch_cp_generic(m->k, m->ca, ra, c, r, 1, g_stream);
         else if (m->kind == kChangepoint) e = launch_cp_rw(m->k, m->ca, ra, c, r, g_stream);
         else if (m->kind == kMixture) e = launch_mix_rw(m->NT, m->ma, ra, c, r, adapt, g_stream);

@@ -295,6 +295,39 @@ RMH_DEV double tail_rows(const double *lt, int g, const double (&v)[28])
     return g == 0 ? t0 : g == 1 ? t1 : g == 2 ? t2 : t3;
 }
 
+// the same sums in five chunks of five k-steps, so that a caller can put MFMAs between a
+// chunk's LDS reads and its FMAs (the reads' latency then hides behind the matrix core)
+struct TailAcc {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    d2_t a[5], b[5];
+    RMH_DEV void load(const double *lt, int g, int chunk)
+    {
+        const d2_t *p = static_cast<const d2_t *>(__builtin_assume_aligned(lt + g * 4, 16));
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            a[q] = p[(5 * chunk + q) * 8];
+            b[q] = p[(5 * chunk + q) * 8 + 1];
+        }
+    }
+    RMH_DEV void fmas(int chunk, const double (&v)[28])
+    {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const double x = v[5 * chunk + q];
+            t0 = fma_(a[q].x, x, t0);
+            t1 = fma_(a[q].y, x, t1);
+            t2 = fma_(b[q].x, x, t2);
+            t3 = fma_(b[q].y, x, t3);
+        }
+    }
+    RMH_DEV double finish(int g)
+    {
+        const double s0 = sum4(t0), s1 = sum4(t1), s2 = sum4(t2), s3 = sum4(t3);
+        return g == 0 ? s0 : g == 1 ? s1 : g == 2 ? s2 : s3;
+    }
+};
+
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
@@ -345,11 +378,15 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
             acc[i].z = th[4 * i + 2];
             acc[i].w = th[4 * i + 3];
         }
+        TailAcc tl;
 #pragma unroll
         for (int s = 0; s < 4 * NF; ++s) {
+            if (s % 5 == 0) tl.load(Lt, g, s / 5);          // chunk s/5: reads now ...
 #pragma unroll
             for (int i = s / 4; i < NF; ++i) acc[i] = mfma(Limg[T::lo(i, s) * 64 + lane], xi[s], acc[i]);
+            if (s % 5 == 4) tl.fmas(s / 5, xi);             // ... FMAs five k-steps of MFMAs later
         }
+        tl.fmas(4, xi);                                     // chunk 4 (k-steps 20..24) was loaded at s = 20
         double thp[S];
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
@@ -358,7 +395,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
             thp[4 * i + 2] = acc[i].z;
             thp[4 * i + 3] = acc[i].w;
         }
-        thp[24] = th[24] + tail_rows(Lt, g, xi);
+        thp[24] = th[24] + tl.finish(g);
         thp[25] = th[25];
         thp[26] = th[26];
         thp[27] = th[27];
@@ -378,6 +415,9 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
             uu += a0.x * a0.x + a0.y * a0.y + a0.z * a0.z + a0.w * a0.w;
             uu += a1.x * a1.x + a1.y * a1.y + a1.z * a1.z + a1.w * a1.w;
         }
+        // (chunking this tail between the MFMAs as in the first product was measured twice --
+        // inside the last pair of row tiles: 37.5 -> 42.4 ms; one chunk per pair: 59 ms -- the
+        // extra live registers spill at the 256-register cap of two waves per SIMD)
         const double ut = tail_rows(Wt, g, y);
         uu += ut * ut;
         uu = sum4(uu);

@@ -124,6 +124,9 @@ struct Tile {
     // Groups of 4 or 8: the xoshiro steps are a serial chain, the four table
     // evaluations of a group are branch-free so that their LDS latencies and
     // Horner chains overlap (a single evaluation is latency-bound, ~400 cycles).
+    // (A step-major variant -- all table reads of one Horner step for the whole group, then
+    // its fmas, one coefficient pair live per normal -- was measured: cfg2 38.5 vs 38.1 ms,
+    // cfg5 23.7 vs 22.4 ms; not kept.)
     static RMH_DEV void normals(Xo &rng, int M, int d, int g, const double *tab, double (&xi)[S])
     {
         constexpr int GRP = 4;

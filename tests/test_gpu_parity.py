@@ -665,3 +665,31 @@ def test_run_to_disk_streams_the_same_samples(ra, tmp_path):
         else:
             with pytest.raises(IndexError):
                 b.current_state()
+
+
+@pytest.mark.parametrize("d", [96, 97, 98, 99, 100, 101])
+def test_gauss_random_walk_around_the_tail_kernel_sizes(ra, orc, d):
+    """d = 97..100 run on k_run_rw_tail (rows 96.. on the VALU), 96 and 101 on the generic
+    kernel: all against the oracle, with a changed .scale re-packing both images."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    g = np.random.default_rng(d)
+    A = g.standard_normal((d, d))
+    Ct = A @ A.T / d + 0.3 * np.eye(d)
+    mu = g.standard_normal(d)
+    Cp = (2.38 ** 2 / d) * Ct
+    th0 = mu + g.standard_normal((70, d))
+    m, om = MultiGaussianDist(mu, Ct), orc.Gaussian(mu, Ct)
+    p = MetropolisRandomWalk(Cp)
+    s = ra.Sampler(m, p, th0, seed=2)
+    s.run(10)
+    ht, hl, acc = oracle_run(orc, om, orc.RandomWalk(Cp), th0, 2, 10)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(s._chain_logpost, hl, rtol=RTOL)
+    p.scale = 0.5
+    s2 = ra.Sampler(m, p, th0, seed=3)
+    s2.run(10)
+    ht, hl, acc = oracle_run(orc, om, orc.RandomWalk(Cp, 0.5), th0, 3, 10)
+    np.testing.assert_array_equal(s2._chain_accept, acc)
+    np.testing.assert_allclose(s2._chain_thetas, ht, rtol=RTOL, atol=1e-12)

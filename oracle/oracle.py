@@ -42,8 +42,8 @@ def lib():
     vp, i64, u64, dbl, i32 = C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_int
     L.orc_log.restype = dbl
     L.orc_log.argtypes = [dbl]
-    L.orc_normal_from_word.restype = dbl
-    L.orc_normal_from_word.argtypes = [u64]
+    L.orc_normal_from_half.restype = dbl
+    L.orc_normal_from_half.argtypes = [C.c_uint32]
     L.orc_rng_seed.argtypes = [u64, u64, i64, _u64p]
     L.orc_rng_stream.argtypes = [_u64p, i64, i32, i32, _f64p, _f64p]
     L.orc_model_gaussian.restype = vp
@@ -140,9 +140,9 @@ def olog(x):
     return lib().orc_log(float(x))
 
 
-def normal_from_word(x):
-    """The standard normal that the 64-bit stream word ``x`` maps to (rmh-rng v2)."""
-    return lib().orc_normal_from_word(int(x))
+def normal_from_half(h):
+    """The standard normal that the 32-bit half word ``h`` of a stream word maps to (rmh-rng v3)."""
+    return lib().orc_normal_from_half(int(h))
 
 
 # ------------------------------------------------------------------ models --

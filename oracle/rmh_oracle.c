@@ -31,7 +31,7 @@
 #endif
 
 /* ------------------------------------------------------------------------- */
-/* 1. "rmh-rng v2": 4 xoshiro256++ sub-streams per chain                       */
+/* 1. "rmh-rng v3": 4 xoshiro256++ sub-streams per chain                       */
 /* ------------------------------------------------------------------------- */
 /*
  * The reference draws from numpy's process-global MT19937:
@@ -43,10 +43,11 @@
  * vectors are made:
  *
  *   chain c (GLOBAL chain id) owns sub-streams g = 0..3, stream id 4c+g;
- *   every iteration each sub-stream draws M = ceil(d/4) 64-bit words, one
- *   standard normal per word (table-driven inverse CDF, below); word m of
- *   sub-stream g is coordinate j = 4m+g (dropped when j >= d); afterwards
- *   sub-stream 0 draws one more word for the accept uniform.
+ *   every iteration each sub-stream draws M = ceil(d/8) 64-bit words, two
+ *   standard normals per word (table-driven inverse CDF of each 32-bit half,
+ *   below); the high half of word m of sub-stream g is coordinate j = 8m+g, the
+ *   low half j = 8m+4+g (dropped when j >= d); afterwards sub-stream 0 draws one
+ *   more word for the accept uniform.
  *
  * Four sub-streams because the HIP kernels put a chain on the four lanes
  * {c, c+16, c+32, c+48} of a wavefront (the B-operand layout of
@@ -135,41 +136,51 @@ double orc_log(double x)
     return dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
 }
 
-/* ---- one standard normal per 64-bit word: table-driven inverse CDF ----------
- * (tools/gen_icdf_table.py documents the construction; the table is this
- * file's own copy, oracle/rmh_icdf_table.h)
- *   sign = x & 1;  q = x | 1;  r = min(clz(q), ROWS-1);  N = (q << r) | 2^63
- *   cell = 8 r + N[62:60];  v = 1 + N[59:8] 2^-52;  t = 2 v - 3
- *   z = Horner_fma(cell polynomial, t), negated when sign is set            */
+/* ---- two standard normals per 64-bit word: table-driven inverse CDF ("rmh-rng v3") ----
+ * (tools/gen_icdf_table.py documents the construction of the table; this file's own copy is
+ * oracle/rmh_icdf_table.h; rows 0..31 of it are used)
+ * Each 32-bit half h of a stream word (high half first) gives one normal:
+ *   sign = h & 1;  q = h | 1;  r = min(clz32(q), 31) = clz32(q);  N = (q << r) | 2^31
+ *   cell = 8 r + N[30:28];  v = 1 + N[27:1] 2^-27;  t = 2 v - 3
+ *   z = Horner_fma(cell polynomial, t), negated when sign is set
+ * i.e. the tail probability p = 2^(-2-r) (1 + (cell + (t+1)/2)/8) read off the half word,
+ * mapped through the normal quantile: exact to 2.1e-16 as a map, on a lattice of 2^-27 in p
+ * within a cell (coarser in the last rows, which have few bits left) and out to |z| = 6.4 (p >= 2^-33) -- what a 32-bit generator offers.
+ * (v2 spent a whole 64-bit word per normal; on MI355X the stream is the largest VALU cost of
+ * the random-walk kernels and f64 MFMA shares the VALU's FP64 units: DESIGN.md section 3.)   */
 #include "rmh_icdf_table.h"
+#define ORC_ICDF_RMAX 31
 
-double orc_normal_from_word(u64 x)
+double orc_normal_from_half(uint32_t h)
 {
-    const u64 q = x | 1ULL;
-    int r = __builtin_clzll(q);
-    if (r > RMH_ICDF_ROWS - 1) r = RMH_ICDF_ROWS - 1;
-    const u64 N = (q << r) | 0x8000000000000000ULL;
-    const int j = (int)(N >> 60) & 7;
-    const u64 mant = (N >> 8) & 0x000FFFFFFFFFFFFFULL;
-    const double v = orc_from_bits(0x3FF0000000000000ULL | mant);
+    const uint32_t q = h | 1u;
+    int r = __builtin_clz(q);
+    if (r > ORC_ICDF_RMAX) r = ORC_ICDF_RMAX;
+    const uint32_t N = (q << r) | 0x80000000u;
+    const int j = (int)(N >> 28) & 7;
+    const u64 m27 = (N >> 1) & 0x7FFFFFFu;
+    const double v = orc_from_bits(0x3FF0000000000000ULL | (m27 << 25));
     const double t = fma(2.0, v, -3.0);
     const double *c = rmh_icdf_table + (size_t)(r * RMH_ICDF_SUB + j) * RMH_ICDF_NC;
     double z = c[RMH_ICDF_NC - 1];
     for (int k = RMH_ICDF_NC - 2; k >= 0; k--) z = fma(z, t, c[k]);
-    return (x & 1ULL) ? -z : z;
+    return (h & 1u) ? -z : z;
 }
 
 #define ORC_2M53 0x1p-53
 
-/* d normals for one chain; st = 16 words [g][4].  Every sub-stream draws
- * M = ceil(d/4) words; word m of sub-stream g is coordinate 4m+g. */
+/* d normals for one chain; st = 16 words [g][4].  Every sub-stream draws M = ceil(d/8)
+ * words; the high half of word m of sub-stream g is coordinate 8m+g, the low half 8m+4+g. */
 void orc_rng_normals(u64 *st, int d, double *xi)
 {
-    const int M = (d + 3) / 4;
+    const int M = (d + 7) / 8;
     for (int g = 0; g < 4; g++)
         for (int m = 0; m < M; m++) {
-            const double z = orc_normal_from_word(orc_next(st + 4 * g));
-            if (4 * m + g < d) xi[4 * m + g] = z;
+            const u64 w = orc_next(st + 4 * g);
+            const double zh = orc_normal_from_half((uint32_t)(w >> 32));
+            const double zl = orc_normal_from_half((uint32_t)w);
+            if (8 * m + g < d) xi[8 * m + g] = zh;
+            if (8 * m + 4 + g < d) xi[8 * m + 4 + g] = zl;
         }
 }
 
@@ -964,7 +975,7 @@ int orc_run_adaptcov(const orc_model *m, const orc_proposal *p, int64_t N, doubl
  * log_likelihood * beta, log_prior unchanged), so its log posterior is
  * Model.log_posterior (model.py:43-55) of (logP, beta * logL).
  *
- * Stream use per sweep and slot (rmh-rng v2 extension): first ONE word from each
+ * Stream use per sweep and slot (rmh-rng extension): first ONE word from each
  * of the slot's four sub-streams -- sub-stream 0's is the selector uniform `u` of
  * ptsampler.py:103, sub-stream 1's the swap uniform of :119, the other two are
  * unused -- then the within-chain draw of Sampler.sample (d normals, accept
@@ -1084,7 +1095,7 @@ int orc_run_pt(const orc_model *m, const orc_proposal *p, int64_t S, double *the
  * rejected (the reference's prior does not bound k; with Poisson(lamb) pieces such states
  * have negligible mass).
  *
- * Stream per iteration (rmh-rng v2 extension): the normals of the 2 KM + 2 padded
+ * Stream per iteration (rmh-rng extension): the normals of the 2 KM + 2 padded
  * coordinates (a block of k entries uses the first k normals of its padded block), then
  * TWO more words from every sub-stream:
  *   first : sub-stream 0 accept uniform, 1..3 the chained block selectors U1, U2, U3

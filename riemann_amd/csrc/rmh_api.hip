@@ -102,7 +102,7 @@ ChainArgs chain_args(const rmh_state *s)
     c.d = s->d;
     c.dp = s->dp;
     c.ks = s->ks;
-    c.M = (s->d + 3) / 4;
+    c.M = (s->d + 7) / 8;   // stream words per sub-stream per iteration: two normals each
     c.icdf = g_icdf;
     return c;
 }

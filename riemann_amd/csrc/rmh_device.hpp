@@ -1,6 +1,6 @@
 // rmh_device.hpp -- device-side random stream and elementary functions (gfx950).
 //
-// "rmh-rng v2" (Random stream): chain c owns four xoshiro256++
+// "rmh-rng v3" (Random stream): chain c owns four xoshiro256++
 // sub-streams g = 0..3 (stream id 4c+g).  In the MFMA kernels the four lanes
 // {cl, cl+16, cl+32, cl+48} of a wavefront hold one chain and lane group g owns
 // sub-stream g and the coordinates j = g (mod 4) -- exactly the B-operand
@@ -217,35 +217,38 @@ RMH_DEV void logistic_terms(double eta, const double *tab, double &lse, double &
     logistic_finish(eta, q, lse, sg);
 }
 
-// ---- one standard normal per 64-bit word: table-driven inverse CDF (rmh-rng v2)
-//   sign = x & 1;  q = x | 1;  r = min(clz(q), ROWS-1);  N = (q << r) | 2^63
-//   cell = 8 r + N[62:60];  v = 1 + N[59:8] 2^-52;  t = 2 v - 3
+// ---- two standard normals per 64-bit word: table-driven inverse CDF (rmh-rng v3)
+// Each 32-bit half h of a stream word (high half first) gives one normal:
+//   sign = h & 1;  q = h | 1;  r = clz32(q) (<= 31);  N = (q << r) | 2^31
+//   cell = 8 r + N[30:28];  v = 1 + N[27:1] 2^-27;  t = 2 v - 3
 //   z = Horner_fma(cell polynomial of degree 10, t), sign applied by xor
-// No division, square root or trigonometry: 11 fma + ~15 integer operations per
-// normal on top of the xoshiro step (Box-Muller cost ~360 cycles per normal; on
-// this chip f64 MFMA and VALU share the SIMD, so every VALU cycle counts).
-// The table (tools/gen_icdf_table.py, worst error 2.1e-16 relative) is staged in
-// LDS with a 96-byte cell stride: six ds_read_b128 per normal.
+// i.e. the tail probability p = 2^(-2-r) (1 + (cell + (t+1)/2)/8) the half word encodes, through
+// the normal quantile: exact to 2.1e-16 as a map, on a lattice of 2^-27 in p within a cell, out
+// to |z| = 6.4.  No division, square root or trigonometry: 11 fma + ~12 integer operations per
+// normal and HALF a xoshiro step (v2 spent a whole 64-bit word per normal: 57 instructions per
+// normal against 42; on this chip f64 MFMA and VALU share the FP64 units, so every VALU cycle
+// counts -- cfg2 38.1 -> 35.4 ms).
+// The table (tools/gen_icdf_table.py, worst error 2.1e-16 relative; rows 0..31 of it) is staged
+// in LDS with a 96-byte cell stride: six ds_read_b128 per normal.
 // Rows are 16 B longer than their 8 cells so that the cells of rows r and r+1
 // (3/4 of all draws) fall on disjoint LDS banks.
-constexpr int kIcdfRows = 56, kIcdfSub = 8, kIcdfNC = 11, kIcdfStride = 12;
+constexpr int kIcdfRows = 32, kIcdfSub = 8, kIcdfNC = 11, kIcdfStride = 12;
 constexpr int kIcdfRowStride = kIcdfSub * kIcdfStride + 2;        // doubles
-constexpr int kIcdfDoubles = kIcdfRows * kIcdfRowStride;          // 5488 = 43 904 B
+constexpr int kIcdfDoubles = kIcdfRows * kIcdfRowStride;          // 3136 = 25 088 B
 
 RMH_DEV void icdf_stage(double *lds_tab, const double *glb_tab)
 {
     for (int i = threadIdx.x; i < kIcdfDoubles; i += blockDim.x) lds_tab[i] = glb_tab[i];
 }
 
-RMH_DEV double normal_from_word(uint64_t x, const double *tab)
+RMH_DEV double normal_from_half(uint32_t h, const double *tab)
 {
-    const uint64_t q = x | 1ULL;
-    int r = __builtin_clzll(q);
-    r = r > kIcdfRows - 1 ? kIcdfRows - 1 : r;
-    const uint64_t N = (q << r) | 0x8000000000000000ULL;
-    const int j = (int)(N >> 60) & 7;
-    const uint64_t mant = (N >> 8) & 0x000FFFFFFFFFFFFFULL;
-    const double v = __longlong_as_double((long long)(0x3FF0000000000000ULL | mant));
+    const uint32_t q = h | 1u;
+    const int r = __builtin_clz(q);
+    const uint32_t N = (q << r) | 0x80000000u;
+    const int j = (int)(N >> 28) & 7;
+    const uint32_t m27 = (N >> 1) & 0x7FFFFFFu;
+    const double v = __longlong_as_double((long long)(0x3FF0000000000000ULL | ((uint64_t)m27 << 25)));
     const double t = fma_(2.0, v, -3.0);
     // 16-byte aligned by construction (table base, 784-B rows, 96-B cells): six ds_read_b128
     typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -263,10 +266,8 @@ RMH_DEV double normal_from_word(uint64_t x, const double *tab)
     z = fma_(z, t, c23.x);
     z = fma_(z, t, c01.y);
     z = fma_(z, t, c01.x);
-    return __longlong_as_double(__double_as_longlong(z) ^ (long long)((x & 1ULL) << 63));
+    return __longlong_as_double(__double_as_longlong(z) ^ ((long long)(h & 1u) << 63));
 }
-
-RMH_DEV double normal_icdf(Xo &x, const double *tab) { return normal_from_word(xo_next(x), tab); }
 
 constexpr double k2m53 = 0x1p-53;
 

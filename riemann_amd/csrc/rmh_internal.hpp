@@ -79,7 +79,7 @@ struct ChainArgs {
     int d;
     int dp;             // rows of theta/grad: 16*NT (MFMA kernels)
     int ks;             // ceil(d/4): history entries hold 4*ks rows
-    int M;              // normals (64-bit words) per sub-stream per iteration: ceil(d/4)
+    int M;              // 64-bit words per sub-stream per iteration: ceil(d/8), two normals per word
     const double *icdf; // inverse-normal-CDF table, 96-byte cell stride (rmh_device.hpp)
     double *adapt;      // AdaptScaleProposal state, 3 rows of ld: Nsamples, Naccepts, scale; or null
     double adapt_target;

@@ -202,12 +202,14 @@ __global__ void __launch_bounds__(256) k_big_rw(GaussArgs m, RwArgs pr, ChainArg
 
     for (int64_t t = 0; t < run.T; ++t) {
         asm volatile("" ::: "memory"); // nothing of an iteration is hoisted out of the loop
-        // 1. waves 0..CB-1: the iteration's normals of their block, word m of sub-stream g = coordinate 4m + g
+        // 1. waves 0..CB-1: the iteration's normals of their block (two per word, rmh-rng v3)
         if (w < CB) {
             double *Yw = Y + jw * ystride;
-            for (int mm = 0; mm < ch.M; ++mm) {
-                const double z = normal_from_word(xo_next(rng), tab);
-                Yw[mm * 64 + lane] = (4 * mm + g < ch.d) ? z : 0.0;
+            for (int mm = 0; mm < ch.M; ++mm) { // Y[s] is coordinate 4s + g: halves of word mm -> s = 2mm, 2mm+1
+                const uint64_t wd = xo_next(rng);
+                const double zh = normal_from_half((uint32_t)(wd >> 32), tab), zl = normal_from_half((uint32_t)wd, tab);
+                Yw[(2 * mm) * 64 + lane] = (8 * mm + g < ch.d) ? zh : 0.0;
+                if (2 * mm + 1 < 4 * NT) Yw[(2 * mm + 1) * 64 + lane] = (8 * mm + 4 + g < ch.d) ? zl : 0.0;
             }
         }
         __syncthreads();

@@ -507,10 +507,13 @@ __global__ void __launch_bounds__(256) k_cprj_run(CpRjArgs m, ChainArgs ch, RunA
 
     for (int64_t t = 0; t < run.T; ++t) {
         asm volatile("" ::: "memory");
-        // normals of the padded coordinates: word mm of sub-stream g is coordinate 4 mm + g
-        for (int mm = 0; mm < (Dn + 3) / 4; ++mm) { // the normals cover the 2 KM + 2 padded coordinates
-            const double z = normal_from_word(xo_next(rng), tab);
-            if (4 * mm + g < Dn) xw[4 * mm + g] = z;
+        // normals of the padded coordinates: the halves of word mm of sub-stream g are the
+        // coordinates 8 mm + g and 8 mm + 4 + g
+        for (int mm = 0; mm < (Dn + 7) / 8; ++mm) { // the normals cover the 2 KM + 2 padded coordinates
+            const uint64_t w = xo_next(rng);
+            const double zh = normal_from_half((uint32_t)(w >> 32), tab), zl = normal_from_half((uint32_t)w, tab);
+            if (8 * mm + g < Dn) xw[8 * mm + g] = zh;
+            if (8 * mm + 4 + g < Dn) xw[8 * mm + 4 + g] = zl;
         }
         const double w1 = u01(xo_next(rng)), w2 = u01(xo_next(rng));
         const double uacc = __shfl(w1, cl), U1 = __shfl(w1, 16 + cl), U2 = __shfl(w1, 32 + cl), U3 = __shfl(w1, 48 + cl);

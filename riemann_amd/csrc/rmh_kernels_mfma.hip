@@ -493,11 +493,13 @@ __global__ void k_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const doub
     if (blk >= ld / 16) return;
     const int64_t c = blk * 16 + cl, slot = blk * 64 + lane, nslots = 4 * ld;
     Xo x = xo_load(rng, nslots, slot);
-    const int M = (d + 3) / 4;
+    const int Mw = (d + 7) / 8;
     for (int t = 0; t < T; ++t) {
-        for (int m = 0; m < M; ++m) {
-            const double z = normal_icdf(x, tab);
-            if (4 * m + g < d) xi[((int64_t)t * ld + c) * d + 4 * m + g] = z;
+        for (int m = 0; m < Mw; ++m) {
+            const uint64_t w = xo_next(x);
+            const double zh = normal_from_half((uint32_t)(w >> 32), tab), zl = normal_from_half((uint32_t)w, tab);
+            if (8 * m + g < d) xi[((int64_t)t * ld + c) * d + 8 * m + g] = zh;
+            if (8 * m + 4 + g < d) xi[((int64_t)t * ld + c) * d + 8 * m + 4 + g] = zl;
         }
         const double uu = Tile<1>::accept_uniform(x, g, cl);
         if (g == 0) u[(int64_t)t * ld + c] = uu;

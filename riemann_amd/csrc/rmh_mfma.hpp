@@ -119,29 +119,31 @@ struct Tile {
         }
     }
 
-    // S normals for this lane: M = ceil(d/4) words of the lane's sub-stream, word
-    // m is coordinate 4m+g; zero beyond d (rmh-rng v2).  tab = ICDF table in LDS.
-    // Groups of 4 or 8: the xoshiro steps are a serial chain, the four table
-    // evaluations of a group are branch-free so that their LDS latencies and
-    // Horner chains overlap (a single evaluation is latency-bound, ~400 cycles).
+    // S normals for this lane: Mw = ceil(d/8) words of the lane's sub-stream, two normals per
+    // word -- the high half of word m is coordinate 8m+g (register 2m), the low half 8m+4+g
+    // (register 2m+1); zero beyond d (rmh-rng v3).  tab = ICDF table in LDS.
+    // Groups of 4 normals (2 words): the xoshiro steps are a serial chain, the four table
+    // evaluations of a group are branch-free so that their LDS latencies and Horner chains
+    // overlap (a single evaluation is latency-bound, ~400 cycles).
     // (A step-major variant -- all table reads of one Horner step for the whole group, then
-    // its fmas, one coefficient pair live per normal -- was measured: cfg2 38.5 vs 38.1 ms,
-    // cfg5 23.7 vs 22.4 ms; not kept.)
-    static RMH_DEV void normals(Xo &rng, int M, int d, int g, const double *tab, double (&xi)[S])
+    // its fmas, one coefficient pair live per normal -- was measured with the v2 stream: cfg2
+    // 38.5 vs 38.1 ms, cfg5 23.7 vs 22.4 ms; not kept.)
+    static RMH_DEV void normals(Xo &rng, int Mw, int d, int g, const double *tab, double (&xi)[S])
     {
         constexpr int GRP = 4;
 #pragma unroll
         for (int m0 = 0; m0 < S; m0 += GRP) {
-            if (m0 < M) {
-                uint64_t w[GRP];
+            if (m0 < 2 * Mw) {
+                uint64_t w[GRP / 2];
 #pragma unroll
-                for (int k = 0; k < GRP; ++k) {
+                for (int k = 0; k < GRP / 2; ++k) {
                     w[k] = 0;
-                    if (m0 + k < M) w[k] = xo_next(rng);
+                    if (m0 / 2 + k < Mw) w[k] = xo_next(rng);
                 }
 #pragma unroll
                 for (int k = 0; k < GRP; ++k) {
-                    const double z = normal_from_word(w[k], tab);
+                    const uint32_t h = (k & 1) ? (uint32_t)w[k / 2] : (uint32_t)(w[k / 2] >> 32);
+                    const double z = normal_from_half(h, tab);
                     xi[m0 + k] = (4 * (m0 + k) + g < d) ? z : 0.0;
                 }
             } else {

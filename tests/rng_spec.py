@@ -1,4 +1,4 @@
-"""Pure-Python restatement of the "rmh-rng v2" stream (oracle/rmh_oracle.c
+"""Pure-Python restatement of the "rmh-rng v3" stream (oracle/rmh_oracle.c
 section 1; DESIGN.md "Random stream"): Python integers for xoshiro256++ and
 exact rational arithmetic for every fma, so that it shares no code and no
 floating-point library with the C oracle or the HIP kernels.  Slow: tests only.
@@ -95,35 +95,38 @@ def table():
     return _TABLE
 
 
-def normal_from_word(x):
-    """rmh-rng v2: one standard normal per 64-bit word (tools/gen_icdf_table.py)."""
+def normal_from_half(h):
+    """rmh-rng v3: one standard normal per 32-bit half of a stream word
+    (tools/gen_icdf_table.py; rows 0..31 of the table)."""
     tab = table()
-    rows = tab.shape[0]
-    q = x | 1
-    r = min(64 - q.bit_length(), rows - 1)
-    N = ((q << r) & M64) | (1 << 63)
-    j = (N >> 60) & 7
-    mant = (N >> 8) & 0x000FFFFFFFFFFFFF
-    v = frombits(0x3FF0000000000000 | mant)
+    q = h | 1
+    r = min(32 - q.bit_length(), 31)
+    N = ((q << r) & 0xFFFFFFFF) | (1 << 31)
+    j = (N >> 28) & 7
+    m27 = (N >> 1) & 0x7FFFFFF
+    v = frombits(0x3FF0000000000000 | (m27 << 25))
     t = fma(2.0, v, -3.0)
     c = tab[r, j]
     z = float(c[-1])
     for k in range(len(c) - 2, -1, -1):
         z = fma(z, t, float(c[k]))
-    return -z if (x & 1) else z
+    return -z if (h & 1) else z
 
 
 def stream_normals_uniform(seed, chain, d, T):
     """xi (T,d), u (T,) of GLOBAL chain id `chain`."""
     st = [stream_init(seed, 4 * chain + g) for g in range(4)]
-    M = (d + 3) // 4
+    M = (d + 7) // 8
     xi = np.zeros((T, d))
     u = np.zeros(T)
     for t in range(T):
         for g in range(4):
             for m in range(M):
-                z = normal_from_word(nxt(st[g]))
-                if 4 * m + g < d:
-                    xi[t, 4 * m + g] = z
+                w = nxt(st[g])
+                zh, zl = normal_from_half(w >> 32), normal_from_half(w & 0xFFFFFFFF)
+                if 8 * m + g < d:
+                    xi[t, 8 * m + g] = zh
+                if 8 * m + 4 + g < d:
+                    xi[t, 8 * m + 4 + g] = zl
         u[t] = float(nxt(st[0]) >> 11) * 2.0 ** -53
     return xi, u

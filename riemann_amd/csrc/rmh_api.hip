@@ -363,7 +363,7 @@ int rmh_model_gaussian_create(const double *mu, const double *L, int d, rmh_mode
     if (d < 1) return fail(RMH_ERR_PARAM, "gaussian: d must be >= 1");
     const bool big = nt_for_dim(d) < 0;
     const int NT = big ? nt_big(d) : nt_for_dim(d);
-    if (NT < 0) return fail(RMH_ERR_PARAM, "gaussian: d > 896 is not supported");
+    if (NT < 0) return fail(RMH_ERR_PARAM, "gaussian: d > 1024 is not supported");
     if (!lower_ok(L, d))
         return fail(RMH_ERR_PARAM, "gaussian: L must be a lower-triangular Cholesky factor");
     // W = L^-1 by forward substitution (columns of the identity)
@@ -657,7 +657,7 @@ int rmh_proposal_rw_create(const double *L, int d, double scale, rmh_proposal_t 
     RMH_NEED_INIT();
     if (d < 1) return fail(RMH_ERR_PARAM, "random walk: d must be >= 1");
     const int NT = nt_for_dim(d) < 0 ? nt_big(d) : nt_for_dim(d);
-    if (NT < 0) return fail(RMH_ERR_PARAM, "random walk: d > 896 is not supported");
+    if (NT < 0) return fail(RMH_ERR_PARAM, "random walk: d > 1024 is not supported");
     if (!lower_ok(L, d))
         return fail(RMH_ERR_PARAM, "random walk: L must be a lower-triangular Cholesky factor");
     rmh_proposal *p = new rmh_proposal;

@@ -16,7 +16,7 @@
 // (global-scope types of the C ABI; their members are kernel argument blocks of namespace rmh)
 struct rmh_model {
     int kind = 0, d = 0, NT = 0;
-    bool big = false; // 112 < d <= 896: rmh_kernels_big.hip (Gaussian, value only)
+    bool big = false; // 112 < d <= 1024: rmh_kernels_big.hip (Gaussian, value only)
     // gaussian
     double *d_W = nullptr, *d_WT = nullptr, *d_mu = nullptr, *d_Wtail = nullptr;
     rmh::GaussArgs ga{};

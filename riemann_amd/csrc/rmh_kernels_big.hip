@@ -1,4 +1,4 @@
-// rmh_kernels_big.hip -- the Gaussian / random-walk path for 112 < d <= 896.
+// rmh_kernels_big.hip -- the Gaussian / random-walk path for 112 < d <= 1024.
 //
 // Same arithmetic as k_run_rw<GaussModel> (rmh_run.hpp): theta' = theta + scale L xi
 // (riemann/proposals/randomwalk.py:21-26), logL = -(|W(theta'-mu)|^2 + d log 2pi +
@@ -7,9 +7,9 @@
 // wavefronts owns CB blocks of 16 chains (CB = 4, 2 or 1 as d grows):
 //   * the B operand of both triangular products (xi, then theta' - mu) lives in LDS in the
 //     B-operand layout, Y[block][s][lane] = coordinate 4s + (lane>>4) of chain lane&15:
-//     128 d bytes per block, which with the inverse-CDF table bounds CB d at ~900;
+//     128 d bytes per block, which with the inverse-CDF table bounds CB d at 1024;
 //   * output tile i (rows 16i..16i+15) belongs to wave i mod 4 for ALL blocks: the wave keeps
-//     its tiles of the candidates theta' in registers and uses every image tile it loads for
+//     its tiles (<= 16) of the candidates theta' in registers and uses every image tile it loads for
 //     CB MFMAs -- the tile images of L and W = Lt^-1 stream from L2 (3.3 MB at d = 896) and
 //     that stream, not the matrix core, is the bound of this kernel;
 //   * wave j (j < CB) holds the random streams of block j, draws its normals (the stream
@@ -355,14 +355,15 @@ static hipError_t big_rw_launch(int NT, const GaussArgs &m, const RwArgs &p, con
 }
 
 // chain blocks per workgroup: as many as the LDS holds (each image tile loaded from L2 then
-// feeds that many MFMAs) -- 4 up to d = 224, 2 up to d = 448, 1 beyond
+// feeds that many MFMAs) -- 4 up to d = 256 (one block per wave at most: wave j owns block j's
+// streams), 2 up to d = 512, 1 up to d = 1024
 hipError_t launch_big_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                                const RunArgs &r, hipStream_t st)
 {
     if (NT <= 8) return big_rw_launch<2, 4>(NT, m, p, c, r, st);
-    if (NT <= 14) return big_rw_launch<4, 4>(NT, m, p, c, r, st);
-    if (NT <= 28) return big_rw_launch<7, 2>(NT, m, p, c, r, st);
-    if (NT <= 56) return big_rw_launch<14, 1>(NT, m, p, c, r, st);
+    if (NT <= 16) return big_rw_launch<4, 4>(NT, m, p, c, r, st);
+    if (NT <= 32) return big_rw_launch<8, 2>(NT, m, p, c, r, st);
+    if (NT <= 64) return big_rw_launch<16, 1>(NT, m, p, c, r, st);
     return hipErrorInvalidValue;
 }
 

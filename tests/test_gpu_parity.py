@@ -568,7 +568,7 @@ def test_g15_gauss200d_vs_reference_fixture(ra):
     check_run(z, s)
 
 
-@pytest.mark.parametrize("d,N", [(113, 50), (128, 33), (257, 16), (500, 40), (896, 17)])
+@pytest.mark.parametrize("d,N", [(113, 50), (128, 33), (256, 70), (257, 16), (500, 40), (513, 20), (1024, 17)])
 def test_gauss_random_walk_big_d_vs_oracle(ra, orc, d, N):
     """Sizes either side of every tile-count bucket of rmh_kernels_big.hip, ragged chain counts,
     burn/thin/resume bookkeeping, log densities through the eval kernel."""
@@ -607,7 +607,7 @@ def test_gauss_random_walk_big_d_vs_oracle(ra, orc, d, N):
 def test_dimension_limit_is_reported(ra):
     from riemann_amd.models import MultiGaussianDist
     with pytest.raises(ra.ParameterError):
-        MultiGaussianDist(np.zeros(897), np.eye(897))
+        MultiGaussianDist(np.zeros(1025), np.eye(1025))
 
 
 def test_g16_the_reference_example_run(ra):

@@ -13,7 +13,7 @@ from riemann_amd.models import MultiGaussianDist                  # noqa: E402
 from riemann_amd.proposals import MetropolisRandomWalk            # noqa: E402
 
 N = 65536
-for d, T in ((128, 200), (256, 100), (512, 40), (896, 20)):
+for d, T in ((128, 200), (256, 100), (512, 40), (1024, 16)):
     g = np.random.default_rng(d)
     Ct = 0.1 * np.eye(d) + 0.9 * np.ones((d, d))
     m = MultiGaussianDist(np.zeros(d), Ct)

@@ -70,11 +70,11 @@ def one(g, it):
     kind = g.choice(["gauss", "gauss", "logreg", "mix", "cp", "bigd", "cprj"])
     if kind == "cprj":
         return one_cprj(g)
-    dmax = {"gauss": 112, "logreg": 112, "mix": 40, "cp": 18, "bigd": 896}[kind]
+    dmax = {"gauss": 112, "logreg": 112, "mix": 40, "cp": 18, "bigd": 1024}[kind]
     d = int(g.choice([1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 111, 112, int(g.integers(1, 113))]))
     d = min(d, dmax)
     if kind == "bigd":
-        d = int(g.choice([113, 127, 128, 129, 224, 225, 300, 448, 449, int(g.integers(113, 600))]))
+        d = int(g.choice([113, 127, 128, 129, 256, 257, 300, 512, 513, int(g.integers(113, 700))]))
     if kind == "cp":
         kc = int(g.integers(1, 9))
         d = 2 * kc + 2

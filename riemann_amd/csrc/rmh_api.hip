@@ -471,21 +471,22 @@ int rmh_model_logreg_create(const double *X, const double *y, int64_t n, int d, 
     if (!(tau2 > 0)) return fail(RMH_ERR_PARAM, "logreg: tau2 must be positive");
     const int NT = nt_for_dim(d);
     if (NT < 0) return fail(RMH_ERR_PARAM, "logreg: d > 112 is not supported by the MFMA tile yet");
-    // stage images of 2 row tiles each (layout: LogRegModel, rmh_models.hpp)
-    const int64_t nchunks = (n + 31) / 32;
-    const int XT = 256 * NT, CHD = 2 * XT + 128;
+    // stage images of kLogRegCH row tiles each (layout: LogRegModel, rmh_models.hpp)
+    constexpr int CH = kLogRegCH, RPS = 16 * CH;   // data rows per stage
+    const int64_t nchunks = (n + RPS - 1) / RPS;
+    const int XT = 256 * NT, CHD = kChunkDoubles(NT);
     std::vector<double> img((size_t)nchunks * CHD, 0.0);
     for (int64_t row = 0; row < n; ++row) {
-        double *ch = &img[(size_t)(row / 32) * CHD];
-        const int k2 = (int)((row / 16) & 1), i = (int)(row & 15);
+        double *ch = &img[(size_t)(row / RPS) * CHD];
+        const int k2 = (int)((row % RPS) / 16), i = (int)(row & 15);
         double *t = ch + k2 * XT;
         for (int k = 0; k < d; ++k) {
             const int s = k >> 2, gg = k & 3;
             const int F = ((s & 3) << 2) | gg;
             t[s * 64 + gg * 16 + (i ^ F)] = X[row * d + k];
         }
-        ch[2 * XT + k2 * 32 + i] = y[row];
-        ch[2 * XT + k2 * 32 + 16 + i] = 1.0;
+        ch[CH * XT + k2 * 32 + i] = y[row];
+        ch[CH * XT + k2 * 32 + 16 + i] = 1.0;
     }
     rmh_model *m = new rmh_model;
     m->kind = kLogReg;

@@ -120,6 +120,11 @@ struct HmcArgs {
     double minv;
 };
 
+// logistic model: row tiles (of 16 data rows) per LDS stage and doubles per stage image
+// (LogRegModel, rmh_models.hpp); the y / weight block of a stage is CH x 32 <= 128 doubles
+constexpr int kLogRegCH = 2; // 3 fits the LDS since the v3 table but was measured slower (MALA 0.63 -> 0.41: spills)
+constexpr int kChunkDoubles(int NT) { return kLogRegCH * 256 * NT + 128; }
+
 // tile counts of the triangular images
 constexpr int tri_tiles(int NT) { return 2 * NT * (NT + 1); }
 inline int nt_for_dim(int d) { return d <= 16 ? 1 : d <= 32 ? 2 : d <= 64 ? 4 : d <= 112 ? 7 : -1; }

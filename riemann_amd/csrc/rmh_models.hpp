@@ -189,8 +189,6 @@ struct MixModel {
 // banks) -- a first version with F = ((s&3)<<2)|((k&3)>>1<<1) was 2-way
 // conflicted under the latter (SQ_LDS_BANK_CONFLICT = 30 % of LDS cycles).
 // So X is stored, moved and staged exactly once.
-constexpr int kLogRegCH = 2;
-constexpr int kChunkDoubles(int NT) { return kLogRegCH * 256 * NT + 128; }
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;

@@ -127,7 +127,7 @@ constexpr int kChunkDoubles(int NT) { return kLogRegCH * 256 * NT + 128; }
 
 // tile counts of the triangular images
 constexpr int tri_tiles(int NT) { return 2 * NT * (NT + 1); }
-inline int nt_for_dim(int d) { return d <= 16 ? 1 : d <= 32 ? 2 : d <= 64 ? 4 : d <= 112 ? 7 : -1; }
+inline int nt_for_dim(int d) { return d <= 16 ? 1 : d <= 112 ? (d + 15) / 16 : -1; }
 // 112 < d <= 1024: the workgroup-per-16-chains kernels of rmh_kernels_big.hip (Gaussian model,
 // random walk): ceil(d/16) tiles, -1 beyond
 constexpr int kBigMaxDim = 1024;

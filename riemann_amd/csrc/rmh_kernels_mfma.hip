@@ -25,7 +25,10 @@ static hipError_t launch(K kernel, int64_t nblocks, int nw, size_t lds_bytes, hi
     switch (NT) {                                    \
     case 1: { constexpr int kNT = 1; __VA_ARGS__; }  \
     case 2: { constexpr int kNT = 2; __VA_ARGS__; }  \
+    case 3: { constexpr int kNT = 3; __VA_ARGS__; }  \
     case 4: { constexpr int kNT = 4; __VA_ARGS__; }  \
+    case 5: { constexpr int kNT = 5; __VA_ARGS__; }  \
+    case 6: { constexpr int kNT = 6; __VA_ARGS__; }  \
     case 7: { constexpr int kNT = 7; __VA_ARGS__; }  \
     default: return hipErrorInvalidValue;            \
     }
@@ -55,7 +58,7 @@ hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const Ch
         // d > 64: the two tile images fill the LDS of a CU, so one workgroup per CU;
         // eight waves give every SIMD a second wavefront to cover the s_waitcnt
         // stalls (LDS table reads of the normals, state/record traffic): +16 %
-        constexpr int NW = (kNT >= 7) ? 8 : 4;
+        constexpr int NW = (kNT >= 5) ? 8 : 4;
         if (adapt) return launch(k_run_rw<M, NW, true, false>, c.nblocks, NW, lds, st, m, p, c, r);
         return launch(k_run_rw<M, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);
     })
@@ -76,7 +79,7 @@ hipError_t launch_gauss_pt(int NT, const GaussArgs &m, const RwArgs &p, const Ch
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
         const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false) + kIcdfDoubles);
-        constexpr int NW = (kNT >= 7) ? 8 : 4;
+        constexpr int NW = (kNT >= 5) ? 8 : 4;
         return launch(k_run_rw<M, NW, false, false, true>, c.nblocks, NW, lds, st, m, p, c, r);
     })
 }
@@ -248,7 +251,7 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
         // second wave cannot overlap VALU with MFMA on this chip, but it fills the
         // s_waitcnt / barrier gaps of the stage loop: 0.52 -> 0.61 of the FP64 roof,
         // although the 256-register cap costs ~300 spilled registers outside the loop.
-        constexpr int NW = (kNT >= 7) ? 8 : 4;
+        constexpr int NW = (kNT >= 5) ? 8 : 4;
         if (r.pt_K > 0) // parallel tempering: plain HMC / MALA within the rungs
             return launch(k_run_hmc<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
         if (p.chM) { // mass-matrix variant: one wave per SIMD (register budget)

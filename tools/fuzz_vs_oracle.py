@@ -70,8 +70,9 @@ def one(g, it):
     kind = g.choice(["gauss", "gauss", "logreg", "mix", "cp", "bigd", "cprj"])
     if kind == "cprj":
         return one_cprj(g)
-    dmax = {"gauss": 112, "logreg": 112, "mix": 40, "cp": 18, "bigd": 1024}[kind]
-    d = int(g.choice([1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 111, 112, int(g.integers(1, 113))]))
+    dmax = {"gauss": 112, "logreg": 112, "mix": 100, "cp": 18, "bigd": 1024}[kind]
+    d = int(g.choice([1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 79, 80, 81, 95, 96, 97, 100, 111, 112,
+                      int(g.integers(1, 113)), int(g.integers(33, 97))]))
     d = min(d, dmax)
     if kind == "bigd":
         d = int(g.choice([113, 127, 128, 129, 256, 257, 300, 512, 513, int(g.integers(113, 700))]))

@@ -142,7 +142,7 @@ hipError_t launch_gauss_eval(int NT, const GaussArgs &m, const ChainArgs &c, int
 hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                            const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_gauss_rw_tail(const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
-                                const RunArgs &r, hipStream_t st);
+                                const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_gauss_pt(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                            const RunArgs &r, hipStream_t st);
 hipError_t launch_mix_eval(int NT, const MixArgs &m, const ChainArgs &c, int want_grad, double *lp_out,

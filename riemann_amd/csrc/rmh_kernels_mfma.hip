@@ -64,12 +64,15 @@ hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const Ch
     })
 }
 
-// d = 97..100, plain random walk: rows 96..99 on the VALU (k_run_rw_tail)
+// d = 97..100, random walk (plain, per-chain adapted scale, or within parallel tempering when
+// r.pt_K > 0): rows 96..99 on the VALU (k_run_rw_tail)
 hipError_t launch_gauss_rw_tail(const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
-                                const RunArgs &r, hipStream_t st)
+                                const RunArgs &r, bool adapt, hipStream_t st)
 {
     const size_t lds = sizeof(double) * (2 * tri_tiles(6) * 64 + 2 * kTailDoubles + 4 * 28 + kIcdfDoubles);
-    return launch(k_run_rw_tail<8>, c.nblocks, 8, lds, st, m, p, c, r);
+    if (r.pt_K > 0) return launch(k_run_rw_tail<8, false, true>, c.nblocks, 8, lds, st, m, p, c, r);
+    if (adapt) return launch(k_run_rw_tail<8, true, false>, c.nblocks, 8, lds, st, m, p, c, r);
+    return launch(k_run_rw_tail<8, false, false>, c.nblocks, 8, lds, st, m, p, c, r);
 }
 
 // parallel tempering over a Gaussian target: one wave per SIMD (register budget)

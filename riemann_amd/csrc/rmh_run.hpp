@@ -76,6 +76,76 @@ struct AdaptScale {
     }
 };
 
+// One lane's share of a parallel-tempering sweep (PTSampler, samplers/ptsampler.py:42-127;
+// layout and rules in the header of k_run_rw below).  Shared by the random-walk kernels.
+struct PtLane {
+    int rung = 0, ebase = 0;
+    bool valid = false, init = false, partner = false;
+    double beta = 1.0, sP = 0.0, sL = 0.0, vswap = 0.0;
+
+    RMH_DEV void setup(const RunArgs &run, int cl, int64_t c)
+    {
+        const int K = run.pt_K;
+        rung = cl % K;
+        ebase = cl - rung;
+        valid = cl < (16 / K) * K;
+        beta = run.pt_beta[c];
+    }
+    // log posterior of the tempered model at (prior, likelihood) parts (ptsampler.py:35-39)
+    RMH_DEV double tempered(const double (&parts)[2]) const { return combine_post(parts[0], beta * parts[1]); }
+    // first words of the sweep: selector (sub-stream 0) and swap uniform (sub-stream 1), then the
+    // sequential "already swapped" rule of ptsampler.py:104-107 from one ballot
+    RMH_DEV void select(const RunArgs &run, Xo &rng, int cl)
+    {
+        const double uw = u01(xo_next(rng));
+        const double usel = __shfl(uw, cl);
+        vswap = __shfl(uw, 16 + cl);
+        // ptsampler.py:107: within-chain iff u > Pswap or last rung
+        const bool wants = valid && rung < run.pt_K - 1 && !(usel > run.pt_pswap);
+        const unsigned wm = (unsigned)(__ballot(wants) & 0xFFFFu) >> ebase;
+        bool prev = false;
+        init = partner = false;
+        for (int j = 0; j < run.pt_K; ++j) { // :104-106, rungs in order
+            const bool in = ((wm >> j) & 1u) && !prev;
+            if (j == rung) {
+                init = in;
+                partner = prev;
+            }
+            prev = in;
+        }
+    }
+    RMH_DEV bool within(bool acc_ok) const { return acc_ok && valid && !init && !partner; }
+    // after the within-chain step: swap proposal between rung i (initiator) and i+1,
+    // ptsampler.py:110-125; returns the accept code of this slot
+    template <int S>
+    RMH_DEV int swap(int lane, bool acc_ok, const double (&parts)[2], double (&th)[S], double &lp)
+    {
+        sP = acc_ok ? parts[0] : sP;
+        sL = acc_ok ? parts[1] : sL;
+        const bool swapper = init || partner;
+        const int src = init ? lane + 1 : partner ? lane - 1 : lane;
+        const double oP = __shfl(sP, src), oL = __shfl(sL, src), ob = __shfl(beta, src);
+        const double olp = __shfl(lp, src), ov = __shfl(vswap, src);
+        const double cross_me = combine_post(oP, beta * oL);  // my model at the other state
+        const double cross_ot = combine_post(sP, ob * sL);    // the other model at my state
+        // (logpost_ji + logpost_ij) - (logpost_ii + logpost_jj): the same bits on both lanes
+        const double delta = (cross_ot + cross_me) - (init ? lp + olp : olp + lp);
+        // U < min(1, exp(D)) restated as log(U) < min(0, D)  (the initiator's uniform)
+        const bool sw_ok = swapper && mh_accept(delta, 0.0, 0.0, partner ? ov : vswap);
+        if (__any(sw_ok)) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const double o = __shfl(th[s], src);
+                th[s] = sw_ok ? o : th[s];
+            }
+        }
+        sP = sw_ok ? oP : sP;
+        sL = sw_ok ? oL : sL;
+        lp = sw_ok ? cross_me : lp;
+        return swapper ? (sw_ok ? 3 : 2) : (acc_ok ? 1 : 0);
+    }
+};
+
 // ------------------------------------------------------------- random walk --
 // On MI355X v_mfma_f64 and the VALU do not overlap across wavefronts
 // (tools/microbench2.hip): a second resident wave cannot hide VALU work behind
@@ -123,21 +193,14 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
     T::load_state(ch.theta, ch.ld, c, g, th);
     double lp = ch.logpost[c];
     Xo rng = xo_load(ch.rng, ch.nslots, slot);
-    // PT: rung and ensemble base of this slot; log prior / log likelihood of the state
-    int rung = 0, ebase = 0;
-    bool pt_valid = false;
-    double beta = 1.0, sP = 0.0, sL = 0.0;
+    PtLane pt;
     if (PT) {
-        const int K = run.pt_K;
-        rung = cl % K;
-        ebase = cl - rung;
-        pt_valid = cl < (16 / K) * K;
-        beta = run.pt_beta[c];
+        pt.setup(run, cl, c);
         double dummy0[S], parts0[2], lp0;
         M::template eval<false>(mlds, m, false, lane, th, lp0, dummy0, parts0);
-        sP = parts0[0];
-        sL = parts0[1];
-        lp = combine_post(sP, beta * sL);   // Sampler.__init__ of the rung, sampler.py:42
+        pt.sP = parts0[0];
+        pt.sL = parts0[1];
+        lp = pt.tempered(parts0);   // Sampler.__init__ of the rung, sampler.py:42
     }
     Keep keep(run);
     keep.record<NT>(run, ch, 0, c, g, active, th, lp);
@@ -156,26 +219,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
         // the tile images never change, so without this fence LICM hoists their
         // ds_reads out of the loop and spends the whole register file on them
         asm volatile("" ::: "memory");
-        bool pt_init = false, pt_partner = false;
-        double vswap = 0.0;
-        if (PT) {
-            // one word of every sub-stream: selector (sub-stream 0), swap uniform (1)
-            const double uw = u01(xo_next(rng));
-            const double usel = __shfl(uw, cl);
-            vswap = __shfl(uw, 16 + cl);
-            // ptsampler.py:107: within-chain iff u > Pswap or last rung
-            const bool wants = pt_valid && rung < run.pt_K - 1 && !(usel > run.pt_pswap);
-            const unsigned wm = (unsigned)(__ballot(wants) & 0xFFFFu) >> ebase;
-            bool prev = false;
-            for (int j = 0; j < run.pt_K; ++j) { // :104-106, rungs in order
-                const bool in = ((wm >> j) & 1u) && !prev;
-                if (j == rung) {
-                    pt_init = in;
-                    pt_partner = prev;
-                }
-                prev = in;
-            }
-        }
+        if (PT) pt.select(run, rng, cl);
         double xi[S];
         T::normals(rng, ch.M, ch.d, g, tab, xi);
         // theta' = theta + scale * L xi        (randomwalk.py:26; logqratio = 0.0)
@@ -216,40 +260,15 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
             T::unpack(acc, thp);
         }
         M::template eval<false>(mlds, m, false, lane, thp, lpp, dummy, parts);
-        if (PT) lpp = combine_post(parts[0], beta * parts[1]); // TemperedModel, ptsampler.py:35-39
+        if (PT) lpp = pt.tempered(parts); // TemperedModel, ptsampler.py:35-39
         const double u = T::accept_uniform(rng, g, cl);
         bool acc_ok = mh_accept(lpp, lp, logq, u);
-        if (PT) acc_ok = acc_ok && pt_valid && !pt_init && !pt_partner;
+        if (PT) acc_ok = pt.within(acc_ok);
 #pragma unroll
         for (int s = 0; s < S; ++s) th[s] = acc_ok ? thp[s] : th[s];
         lp = acc_ok ? lpp : lp;
         int code = acc_ok ? 1 : 0;
-        if (PT) {
-            sP = acc_ok ? parts[0] : sP;
-            sL = acc_ok ? parts[1] : sL;
-            // swap proposal between rung i (initiator) and i+1, ptsampler.py:110-125
-            const bool swapper = pt_init || pt_partner;
-            const int src = pt_init ? lane + 1 : pt_partner ? lane - 1 : lane;
-            const double oP = __shfl(sP, src), oL = __shfl(sL, src), ob = __shfl(beta, src);
-            const double olp = __shfl(lp, src), ov = __shfl(vswap, src);
-            const double cross_me = combine_post(oP, beta * oL);  // my model at the other state
-            const double cross_ot = combine_post(sP, ob * sL);    // the other model at my state
-            // (logpost_ji + logpost_ij) - (logpost_ii + logpost_jj): the same bits on both lanes
-            const double delta = (cross_ot + cross_me) - (pt_init ? lp + olp : olp + lp);
-            // U < min(1, exp(D)) restated as log(U) < min(0, D)  (the initiator's uniform)
-            const bool sw_ok = swapper && mh_accept(delta, 0.0, 0.0, pt_partner ? ov : vswap);
-            if (__any(sw_ok)) {
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const double o = __shfl(th[s], src);
-                    th[s] = sw_ok ? o : th[s];
-                }
-            }
-            sP = sw_ok ? oP : sP;
-            sL = sw_ok ? oL : sL;
-            lp = sw_ok ? cross_me : lp;
-            code = swapper ? (sw_ok ? 3 : 2) : code;
-        }
+        if (PT) code = pt.swap(lane, acc_ok, parts, th, lp);
         if (ADAPT) ad.adapt(acc_ok, ch.adapt_target);
         if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = (uint8_t)code;
         keep.record<NT>(run, ch, t + 1, c, g, active, th, lp);
@@ -328,7 +347,35 @@ struct TailAcc {
     }
 };
 
-template <int NW>
+// log N(theta | mu, C) from y = theta - mu for d = 97..100: |W y|^2 with row tiles 0..5 on the
+// matrix core (two in flight) and rows 96..99 on the VALU
+RMH_DEV double gauss_loglik(const double *Wimg, const double *Wt, const GaussArgs &m, int lane, int g,
+                        const double (&y)[28])
+{
+    using T = Tile<7>;
+    constexpr int NF = 6;
+    double uu = 0.0;
+#pragma unroll
+    for (int i0 = 0; i0 < NF; i0 += 2) {
+        double4_t a0 = double4_t{0.0, 0.0, 0.0, 0.0}, a1 = a0;
+#pragma unroll
+        for (int s = 0; s < 4 * (i0 + 2); ++s) {
+            if (s < 4 * (i0 + 1)) a0 = mfma(Wimg[T::lo(i0, s) * 64 + lane], y[s], a0);
+            a1 = mfma(Wimg[T::lo(i0 + 1, s) * 64 + lane], y[s], a1);
+        }
+        uu += a0.x * a0.x + a0.y * a0.y + a0.z * a0.z + a0.w * a0.w;
+        uu += a1.x * a1.x + a1.y * a1.y + a1.z * a1.z + a1.w * a1.w;
+    }
+    // (chunking this tail between the MFMAs as in the first product was measured twice --
+    // inside the last pair of row tiles: 37.5 -> 42.4 ms; one chunk per pair: 59 ms -- the
+    // extra live registers spill at the 256-register cap of two waves per SIMD)
+    const double ut = tail_rows(Wt, g, y);
+    uu += ut * ut;
+    uu = sum4(uu);
+    return -0.5 * ((uu + m.dlog2pi) + m.logdetC);
+}
+
+template <int NW, bool ADAPT = false, bool PT = false>
 __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
     constexpr int NT = 7, S = 28, NF = 6, kFull = tri_tiles(NF) * 64; // six full row tiles: 84 tile images
@@ -362,21 +409,35 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
     T::load_state(ch.theta, ch.ld, c, g, th);
     double lp = ch.logpost[c];
     Xo rng = xo_load(ch.rng, ch.nslots, slot);
+    PtLane pt;
+    if (PT) { // MultiGaussianDist: log prior 0, so the state's parts are (0, logL) = (0, lp at beta = 1)
+        pt.setup(run, cl, c);
+        double y0[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) y0[s] = th[s] - mu[4 * s + g];
+        double parts0[2] = {0.0, gauss_loglik(Wimg, Wt, m, lane, g, y0)};
+        pt.sL = parts0[1];
+        lp = pt.tempered(parts0);
+    }
     Keep keep(run);
     keep.record<NT>(run, ch, 0, c, g, active, th, lp);
+    AdaptScale ad{0.0, 0.0, 1.0};
+    if (ADAPT) ad.load(ch, c);
 
     for (int64_t t = 0; t < run.T; ++t) {
         asm volatile("" ::: "memory");
+        if (PT) pt.select(run, rng, cl);
         double xi[S];
         T::normals(rng, ch.M, ch.d, g, tab, xi);
         // theta' = theta + scale * L xi: row tiles 0..5 on the matrix core, rows 96..99 on the VALU
+        // (ADAPT: the chain's own scale times the unscaled image's product, as in k_run_rw)
         double4_t acc[NF];
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
-            acc[i].x = th[4 * i + 0];
-            acc[i].y = th[4 * i + 1];
-            acc[i].z = th[4 * i + 2];
-            acc[i].w = th[4 * i + 3];
+            acc[i].x = ADAPT ? 0.0 : th[4 * i + 0];
+            acc[i].y = ADAPT ? 0.0 : th[4 * i + 1];
+            acc[i].z = ADAPT ? 0.0 : th[4 * i + 2];
+            acc[i].w = ADAPT ? 0.0 : th[4 * i + 3];
         }
         TailAcc tl;
 #pragma unroll
@@ -395,7 +456,13 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
             thp[4 * i + 2] = acc[i].z;
             thp[4 * i + 3] = acc[i].w;
         }
-        thp[24] = th[24] + tl.finish(g);
+        if (ADAPT) {
+#pragma unroll
+            for (int s = 0; s < 4 * NF; ++s) thp[s] = th[s] + ad.scale * thp[s];
+            thp[24] = th[24] + ad.scale * tl.finish(g);
+        } else {
+            thp[24] = th[24] + tl.finish(g);
+        }
         thp[25] = th[25];
         thp[26] = th[26];
         thp[27] = th[27];
@@ -403,37 +470,24 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         double y[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) y[s] = thp[s] - mu[4 * s + g];
-        double uu = 0.0;
-#pragma unroll
-        for (int i0 = 0; i0 < NF; i0 += 2) {
-            double4_t a0 = double4_t{0.0, 0.0, 0.0, 0.0}, a1 = a0;
-#pragma unroll
-            for (int s = 0; s < 4 * (i0 + 2); ++s) {
-                if (s < 4 * (i0 + 1)) a0 = mfma(Wimg[T::lo(i0, s) * 64 + lane], y[s], a0);
-                a1 = mfma(Wimg[T::lo(i0 + 1, s) * 64 + lane], y[s], a1);
-            }
-            uu += a0.x * a0.x + a0.y * a0.y + a0.z * a0.z + a0.w * a0.w;
-            uu += a1.x * a1.x + a1.y * a1.y + a1.z * a1.z + a1.w * a1.w;
-        }
-        // (chunking this tail between the MFMAs as in the first product was measured twice --
-        // inside the last pair of row tiles: 37.5 -> 42.4 ms; one chunk per pair: 59 ms -- the
-        // extra live registers spill at the 256-register cap of two waves per SIMD)
-        const double ut = tail_rows(Wt, g, y);
-        uu += ut * ut;
-        uu = sum4(uu);
-        const double logL = -0.5 * ((uu + m.dlog2pi) + m.logdetC);
-        const double lpp = combine_post(0.0, logL);
+        double parts[2] = {0.0, gauss_loglik(Wimg, Wt, m, lane, g, y)};
+        const double lpp = PT ? pt.tempered(parts) : combine_post(0.0, parts[1]);
         const double u = T::accept_uniform(rng, g, cl);
-        const bool acc_ok = mh_accept(lpp, lp, 0.0, u);
+        bool acc_ok = mh_accept(lpp, lp, 0.0, u);
+        if (PT) acc_ok = pt.within(acc_ok);
 #pragma unroll
         for (int s = 0; s < S; ++s) th[s] = acc_ok ? thp[s] : th[s];
         lp = acc_ok ? lpp : lp;
-        if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = acc_ok ? 1 : 0;
+        int code = acc_ok ? 1 : 0;
+        if (PT) code = pt.swap(lane, acc_ok, parts, th, lp);
+        if (ADAPT) ad.adapt(acc_ok, ch.adapt_target);
+        if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = (uint8_t)code;
         keep.record<NT>(run, ch, t + 1, c, g, active, th, lp);
     }
     if (active) {
         T::store_state(ch.theta, ch.ld, c, g, th);
         if (g == 0) ch.logpost[c] = lp;
+        if (ADAPT && g == 0) ad.store(ch, c);
         xo_store(ch.rng, ch.nslots, slot, rng);
     }
 }

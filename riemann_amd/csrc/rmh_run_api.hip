@@ -361,7 +361,10 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
                               : launch_logreg_hmc(m->NT, m->la, ha, c, r, false, g_stream);
     } else if (K > 0) {
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
-        e = m->kind == kGauss         ? launch_gauss_pt(m->NT, m->ga, ra, c, r, g_stream)
+        const bool tail = m->kind == kGauss && m->ga.Wtail && p->d_Ltail && !getenv("RMH_NO_TAIL");
+        if (tail) ra.Ltail = p->d_Ltail;
+        e = tail                      ? launch_gauss_rw_tail(m->ga, ra, c, r, false, g_stream)
+            : m->kind == kGauss       ? launch_gauss_pt(m->NT, m->ga, ra, c, r, g_stream)
             : m->kind == kLogReg      ? launch_logreg_rw(m->NT, m->la, ra, c, r, false, g_stream)
             : m->kind == kChangepoint ? launch_cp_generic(m->k, m->ca, ra, c, r, 4, g_stream)
                                       : launch_mix_rw(m->NT, m->ma, ra, c, r, false, g_stream);
@@ -383,9 +386,9 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
                 ra.blk_p[b] = p->blk_p[b];
             }
         }
-        if (m->kind == kGauss && !adapt && m->ga.Wtail && p->d_Ltail && !getenv("RMH_NO_TAIL")) {
+        if (m->kind == kGauss && m->ga.Wtail && p->d_Ltail && !getenv("RMH_NO_TAIL")) {
             ra.Ltail = p->d_Ltail;   // d = 97..100: rows 96..99 on the VALU instead of a 7th row tile
-            e = launch_gauss_rw_tail(m->ga, ra, c, r, g_stream);
+            e = launch_gauss_rw_tail(m->ga, ra, c, r, adapt, g_stream);
         } else if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
         else if (m->kind == kChangepoint && adapt) e = launch_cp_generic(m->k, m->ca, ra, c, r, 1, g_stream);
         else if (m->kind == kChangepoint) e = launch_cp_rw(m->k, m->ca, ra, c, r, g_stream);

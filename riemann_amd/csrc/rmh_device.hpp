@@ -273,12 +273,55 @@ constexpr double k2m53 = 0x1p-53;
 
 RMH_DEV double u01(uint64_t r) { return (double)(r >> 11) * k2m53; }
 
-// sum over the four lanes {cl, cl+16, cl+32, cl+48} that hold one chain
+// A chain's four lanes {cl, cl+16, cl+32, cl+48} sit in the four 16-lane rows of the wavefront.
+// Exchanges between rows use the gfx950 row swaps v_permlane16_swap / v_permlane32_swap: plain
+// VALU instructions, where __shfl (ds_bpermute) makes an LDS round trip whose latency the two
+// waves of a SIMD cannot cover (cfg2: 38 bpermutes per iteration, 35.2 -> see DESIGN.md section 5).
+struct RowPair {
+    double a, b;
+};
+// rows of a = {x0, y0, x2, y2}, rows of b = {x1, y1, x3, y3}   (x_r = row r of x)
+RMH_DEV RowPair swap16(double x, double y)
+{
+    const uint64_t ux = (uint64_t)__double_as_longlong(x), uy = (uint64_t)__double_as_longlong(y);
+    const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)ux, (uint32_t)uy, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(ux >> 32), (uint32_t)(uy >> 32), false, false);
+    return {__longlong_as_double((long long)((uint64_t)lo[0] | ((uint64_t)hi[0] << 32))),
+            __longlong_as_double((long long)((uint64_t)lo[1] | ((uint64_t)hi[1] << 32)))};
+}
+// rows of a = {x0, x1, y0, y1}, rows of b = {x2, x3, y2, y3}
+RMH_DEV RowPair swap32(double x, double y)
+{
+    const uint64_t ux = (uint64_t)__double_as_longlong(x), uy = (uint64_t)__double_as_longlong(y);
+    const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)ux, (uint32_t)uy, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(ux >> 32), (uint32_t)(uy >> 32), false, false);
+    return {__longlong_as_double((long long)((uint64_t)lo[0] | ((uint64_t)hi[0] << 32))),
+            __longlong_as_double((long long)((uint64_t)lo[1] | ((uint64_t)hi[1] << 32)))};
+}
+
+// sum over the chain's four lanes: (x0 + x1) + (x2 + x3), the same bits on all four
 RMH_DEV double sum4(double x)
 {
-    x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 32);
-    return x;
+    const RowPair p = swap16(x, x);
+    const double s = p.a + p.b;
+    const RowPair q = swap32(s, s);
+    return q.a + q.b;
+}
+
+// row g receives the sum of t_g over the chain's four lanes (a reduce-scatter of four values:
+// three swaps instead of four sum4); same bits as sum4(t_g)
+RMH_DEV double sum4_scatter(double t0, double t1, double t2, double t3)
+{
+    const RowPair p = swap16(t0, t1), q = swap16(t2, t3);
+    const RowPair r = swap32(p.a + p.b, q.a + q.b);
+    return r.a + r.b;
+}
+
+// the value of row 0 (lane cl) on all four lanes of the chain
+RMH_DEV double bcast_row0(double x)
+{
+    const RowPair p = swap16(x, x);
+    return swap32(p.a, p.a).a;
 }
 
 // Model.log_posterior, riemann/models/model.py:49-55

@@ -160,7 +160,7 @@ struct Tile {
         Xo tmp = rng;
         const uint64_t r = xo_next(tmp);
         if (g == 0) rng = tmp;
-        return __shfl(u01(r), cl);
+        return bcast_row0(u01(r));
     }
 
     // (16*NT, ld) parameter-major state <-> registers.  State arrays are padded

@@ -307,11 +307,7 @@ RMH_DEV double tail_rows(const double *lt, int g, const double (&v)[28])
         t2 = fma_(b.x, v[s], t2);
         t3 = fma_(b.y, v[s], t3);
     }
-    t0 = sum4(t0);
-    t1 = sum4(t1);
-    t2 = sum4(t2);
-    t3 = sum4(t3);
-    return g == 0 ? t0 : g == 1 ? t1 : g == 2 ? t2 : t3;
+    return sum4_scatter(t0, t1, t2, t3);
 }
 
 // the same sums in five chunks of five k-steps, so that a caller can put MFMAs between a
@@ -342,8 +338,7 @@ struct TailAcc {
     }
     RMH_DEV double finish(int g)
     {
-        const double s0 = sum4(t0), s1 = sum4(t1), s2 = sum4(t2), s3 = sum4(t3);
-        return g == 0 ? s0 : g == 1 ? s1 : g == 2 ? s2 : s3;
+        return sum4_scatter(t0, t1, t2, t3);
     }
 };
 

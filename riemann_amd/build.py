@@ -14,8 +14,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libriemann_hip.so")
-SOURCES = ["rmh_api.hip", "rmh_run_api.hip", "rmh_kernels_mfma.hip", "rmh_kernels_cp.hip", "rmh_kernels_big.hip",
-           "rmh_comm.hip"]
+SOURCES = ["rmh_api.hip", "rmh_run_api.hip", "rmh_kernels_mfma.hip", "rmh_kernels_logreg.hip", "rmh_kernels_mix.hip",
+           "rmh_kernels_cp.hip", "rmh_kernels_big.hip", "rmh_comm.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
 
@@ -40,7 +40,7 @@ def build(force=False, verbose=False):
         subprocess.check_call(cmd)
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"])
     return SO

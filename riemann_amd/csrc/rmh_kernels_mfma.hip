@@ -1,37 +1,12 @@
-// rmh_kernels_mfma.hip -- instantiations and launchers of the MFMA kernels
-// (Gaussian and logistic-regression models; random-walk and HMC/MALA proposals)
-// plus the small utility kernels (stream seeding, layout transposes, test hooks).
+// rmh_kernels_mfma.hip -- instantiations and launchers of the MFMA kernels of the Gaussian
+// model (random-walk, pCN, HMC/MALA, parallel tempering), the AdaptCov moment / update kernels
+// and the small utility kernels (stream seeding, layout transposes, test hooks).
+// The logistic and mixture models' instantiations: rmh_kernels_logreg.hip, rmh_kernels_mix.hip
+// (separate translation units so that the three compile in parallel).
 #include "rmh_run.hpp"
+#include "rmh_launch.hpp"
 
 namespace rmh {
-
-template <class K, class... A>
-static hipError_t launch(K kernel, int64_t nblocks, int nw, size_t lds_bytes, hipStream_t st,
-                         A... args)
-{
-    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-    if (lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_bytes);
-        if (e != hipSuccess) return e;
-    }
-    const dim3 grid((unsigned)((nblocks + nw - 1) / nw)), block(64 * nw);
-    hipLaunchKernelGGL(kernel, grid, block, lds_bytes, st, args...);
-    return hipGetLastError();
-}
-
-#define RMH_NT_DISPATCH(NT, ...)                     \
-    switch (NT) {                                    \
-    case 1: { constexpr int kNT = 1; __VA_ARGS__; }  \
-    case 2: { constexpr int kNT = 2; __VA_ARGS__; }  \
-    case 3: { constexpr int kNT = 3; __VA_ARGS__; }  \
-    case 4: { constexpr int kNT = 4; __VA_ARGS__; }  \
-    case 5: { constexpr int kNT = 5; __VA_ARGS__; }  \
-    case 6: { constexpr int kNT = 6; __VA_ARGS__; }  \
-    case 7: { constexpr int kNT = 7; __VA_ARGS__; }  \
-    default: return hipErrorInvalidValue;            \
-    }
 
 // ------------------------------------------------------------------ Gaussian
 hipError_t launch_gauss_eval(int NT, const GaussArgs &m, const ChainArgs &c, int want_grad,
@@ -87,69 +62,6 @@ hipError_t launch_gauss_pt(int NT, const GaussArgs &m, const RwArgs &p, const Ch
     })
 }
 
-// ------------------------------------------------------ mixture of Gaussians
-hipError_t launch_mix_eval(int NT, const MixArgs &m, const ChainArgs &c, int want_grad, double *lp_out,
-                           double *grad_out, double *lprior_out, double *llik_out, hipStream_t st)
-{
-    RMH_NT_DISPATCH(NT, {
-        using M = MixModel<kNT>;
-        if (want_grad)
-            return launch(k_eval<M, true, 4>, c.nblocks, 4, 0, st, m, c, lp_out, grad_out, lprior_out, llik_out);
-        return launch(k_eval<M, false, 4>, c.nblocks, 4, 0, st, m, c, lp_out, grad_out, lprior_out, llik_out);
-    })
-}
-
-hipError_t launch_mix_hmc(int NT, const MixArgs &m, const HmcArgs &p, const ChainArgs &c,
-                          const RunArgs &r, bool adapt, hipStream_t st)
-{
-    RMH_NT_DISPATCH(NT, {
-        using M = MixModel<kNT>;
-        const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
-        if (p.chM) {
-            if (adapt) return launch(k_run_hmc<M, 4, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
-            return launch(k_run_hmc<M, 4, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
-        }
-        if (adapt) return launch(k_run_hmc<M, 4, true, false>, c.nblocks, 4, lds, st, m, p, c, r);
-        return launch(k_run_hmc<M, 4, false, false>, c.nblocks, 4, lds, st, m, p, c, r);
-    })
-}
-
-hipError_t launch_mix_propose_hmc(int NT, const MixArgs &m, const HmcArgs &p, const ChainArgs &c,
-                                  double *theta_p, double *logq, hipStream_t st)
-{
-    RMH_NT_DISPATCH(NT, {
-        using M = MixModel<kNT>;
-        const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
-        if (p.chM) return launch(k_propose_hmc<M, 4, true>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
-        return launch(k_propose_hmc<M, 4, false>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
-    })
-}
-
-hipError_t launch_mix_rw(int NT, const MixArgs &m, const RwArgs &p, const ChainArgs &c,
-                         const RunArgs &r, bool adapt, hipStream_t st)
-{
-    RMH_NT_DISPATCH(NT, {
-        using M = MixModel<kNT>;
-        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + kIcdfDoubles);
-        if (r.pt_K > 0)
-            return launch(k_run_rw<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
-        if (adapt)
-            return launch(k_run_rw<M, 4, true, false, false>, c.nblocks, 4, lds, st, m, p, c, r);
-        return launch(k_run_rw<M, 4, false, false, false>, c.nblocks, 4, lds, st, m, p, c, r);
-    })
-}
-
-hipError_t launch_mix_pcn(int NT, const MixArgs &m, const RwArgs &p, const ChainArgs &c,
-                          const RunArgs &r, bool adapt, hipStream_t st)
-{
-    RMH_NT_DISPATCH(NT, {
-        using M = MixModel<kNT>;
-        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + kIcdfDoubles);
-        if (adapt) return launch(k_run_rw<M, 4, true, true, false>, c.nblocks, 4, lds, st, m, p, c, r);
-        return launch(k_run_rw<M, 4, false, true, false>, c.nblocks, 4, lds, st, m, p, c, r);
-    })
-}
-
 hipError_t launch_gauss_pcn(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                             const RunArgs &r, bool adapt, hipStream_t st)
 {
@@ -195,83 +107,6 @@ hipError_t launch_gauss_propose_hmc(int NT, const GaussArgs &m, const HmcArgs &p
 {
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
-        const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
-        if (p.chM) return launch(k_propose_hmc<M, 4, true>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
-        return launch(k_propose_hmc<M, 4, false>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
-    })
-}
-
-// ------------------------------------------------------- logistic regression
-hipError_t launch_logreg_eval(int NT, const LogRegArgs &m, const ChainArgs &c, int want_grad,
-                              double *lp_out, double *grad_out, double *lprior_out,
-                              double *llik_out, hipStream_t st)
-{
-    RMH_NT_DISPATCH(NT, {
-        using M = LogRegModel<kNT>;
-        const size_t lds = sizeof(double) * M::lds_doubles(true);
-        if (want_grad)
-            return launch(k_eval<M, true, 4>, c.nblocks, 4, lds, st, m, c, lp_out, grad_out,
-                          lprior_out, llik_out);
-        return launch(k_eval<M, false, 4>, c.nblocks, 4, lds, st, m, c, lp_out, grad_out,
-                      lprior_out, llik_out);
-    })
-}
-
-// random walk (plain, AdaptScale, or parallel tempering) on the logistic model: the
-// proposal's tile image stays in global memory, the LDS belongs to the X stages
-hipError_t launch_logreg_rw(int NT, const LogRegArgs &m, const RwArgs &p, const ChainArgs &c,
-                            const RunArgs &r, bool adapt, hipStream_t st)
-{
-    RMH_NT_DISPATCH(NT, {
-        using M = LogRegModel<kNT>;
-        const size_t lds = sizeof(double) * (M::lds_doubles(false) + kIcdfDoubles);
-        if (r.pt_K > 0)
-            return launch(k_run_rw<M, 4, false, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
-        if (adapt)
-            return launch(k_run_rw<M, 4, true, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
-        return launch(k_run_rw<M, 4, false, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
-    })
-}
-
-hipError_t launch_logreg_pcn(int NT, const LogRegArgs &m, const RwArgs &p, const ChainArgs &c,
-                             const RunArgs &r, bool adapt, hipStream_t st)
-{
-    RMH_NT_DISPATCH(NT, {
-        using M = LogRegModel<kNT>;
-        const size_t lds = sizeof(double) * (M::lds_doubles(false) + kIcdfDoubles);
-        if (adapt) return launch(k_run_rw<M, 4, true, true, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
-        return launch(k_run_rw<M, 4, false, true, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
-    })
-}
-
-hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, const ChainArgs &c,
-                             const RunArgs &r, bool adapt, hipStream_t st)
-{
-    RMH_NT_DISPATCH(NT, {
-        using M = LogRegModel<kNT>;
-        const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
-        // d > 64: eight waves per workgroup (two per SIMD, <= 256 registers each).  The
-        // second wave cannot overlap VALU with MFMA on this chip, but it fills the
-        // s_waitcnt / barrier gaps of the stage loop: 0.52 -> 0.61 of the FP64 roof,
-        // although the 256-register cap costs ~300 spilled registers outside the loop.
-        constexpr int NW = (kNT >= 5) ? 8 : 4;
-        if (r.pt_K > 0) // parallel tempering: plain HMC / MALA within the rungs
-            return launch(k_run_hmc<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
-        if (p.chM) { // mass-matrix variant: one wave per SIMD (register budget)
-            if (adapt) return launch(k_run_hmc<M, 4, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
-            return launch(k_run_hmc<M, 4, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
-        }
-        if (adapt) return launch(k_run_hmc<M, NW, true, false>, c.nblocks, NW, lds, st, m, p, c, r);
-        return launch(k_run_hmc<M, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);
-    })
-}
-
-hipError_t launch_logreg_propose_hmc(int NT, const LogRegArgs &m, const HmcArgs &p,
-                                     const ChainArgs &c, double *theta_p, double *logq,
-                                     hipStream_t st)
-{
-    RMH_NT_DISPATCH(NT, {
-        using M = LogRegModel<kNT>;
         const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
         if (p.chM) return launch(k_propose_hmc<M, 4, true>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
         return launch(k_propose_hmc<M, 4, false>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);

@@ -65,14 +65,17 @@ std::vector<double> pack_upper_T(const double *M, int d, int NT)
     return img;
 }
 
+// rows 96..99 of a lower-triangular matrix in the layout k_run_rw_tail reads (rmh_run.hpp,
+// TailAcc): [group S of four k-steps][lane group g][4 q + r] = M[96 + r][4 (4S + q) + g]
 std::vector<double> pack_tail(const double *M, int d, double scale)
 {
-    std::vector<double> t((size_t)25 * 16, 0.0);
+    std::vector<double> t((size_t)7 * 64, 0.0);
     for (int s = 0; s < 25; ++s)
         for (int g = 0; g < 4; ++g)
             for (int r = 0; r < 4; ++r) {
                 const int row = 96 + r, col = 4 * s + g;
-                if (row < d && col < d && col <= row) t[(size_t)(s * 4 + g) * 4 + r] = scale * M[(size_t)row * d + col];
+                if (row < d && col < d && col <= row)
+                    t[(size_t)((s / 4) * 4 + g) * 16 + 4 * (s % 4) + r] = scale * M[(size_t)row * d + col];
             }
     return t;
 }

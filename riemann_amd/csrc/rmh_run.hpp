@@ -292,60 +292,70 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
 // (tile 6, register 0).  1600 MFMA cycles become ~540 VALU cycles per product.
 // Plain MetropolisRandomWalk on MultiGaussianDist only; same results as k_run_rw up to the
 // summation order inside those four rows.
-constexpr int kTailS = 25, kTailDoubles = kTailS * 16;
+// Coefficient layout in LDS: for each group S of four k-steps and lane group g one 16-double row,
+// entry 4 q + r = row 96+r, column 4 (4S+q) + g.  A lane reads ONE entry per group (a conflict-free
+// ds_read_b64 for the wavefront) and the FMAs take the entry they need from the lane that holds
+// it with the DPP row broadcast of v_fmac_f64 (row_newbcast: lane n of the own 16-lane row).
+// The 16 lanes of a row share all their coefficients, so reading four per lane and k-step
+// (2 ds_read_b128, the first version) moved 16x the bytes: those reads cost 2.0 of 34.8 ms.
+constexpr int kTailS = 25, kTailGroups = 7, kTailDoubles = kTailGroups * 64;
 
-RMH_DEV double tail_rows(const double *lt, int g, const double (&v)[28])
+// t <- fma(row-broadcast of lane N of c, x, t)
+template <int N>
+RMH_DEV void fmac_bcast(double &t, double c, double x)
 {
-    typedef double d2_t __attribute__((ext_vector_type(2)));
-    const d2_t *p = static_cast<const d2_t *>(__builtin_assume_aligned(lt + g * 4, 16));
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-#pragma unroll
-    for (int s = 0; s < kTailS; ++s) {
-        const d2_t a = p[s * 8], b = p[s * 8 + 1]; // [s][g][0..1], [s][g][2..3]
-        t0 = fma_(a.x, v[s], t0);
-        t1 = fma_(a.y, v[s], t1);
-        t2 = fma_(b.x, v[s], t2);
-        t3 = fma_(b.y, v[s], t3);
-    }
-    return sum4_scatter(t0, t1, t2, t3);
+    static_assert(N >= 0 && N < 16, "lane of the 16-lane row");
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(c), "v"(x), "n"(N));
 }
 
-// the same sums in five chunks of five k-steps, so that a caller can put MFMAs between a
-// chunk's LDS reads and its FMAs (the reads' latency then hides behind the matrix core)
 struct TailAcc {
-    typedef double d2_t __attribute__((ext_vector_type(2)));
     double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-    d2_t a[5], b[5];
-    RMH_DEV void load(const double *lt, int g, int chunk)
+    double c[kTailGroups];
+    // this lane's entry of group S (lt: the image, g/cl: lane group and lane in the row)
+    RMH_DEV void load(const double *lt, int g, int cl, int S) { c[S] = lt[(S * 4 + g) * 16 + cl]; }
+    // the four rows' FMAs of k-step s = 4 S + Q
+    template <int S, int Q>
+    RMH_DEV void step(double x)
     {
-        const d2_t *p = static_cast<const d2_t *>(__builtin_assume_aligned(lt + g * 4, 16));
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            a[q] = p[(5 * chunk + q) * 8];
-            b[q] = p[(5 * chunk + q) * 8 + 1];
+        fmac_bcast<4 * Q + 0>(t0, c[S], x);
+        fmac_bcast<4 * Q + 1>(t1, c[S], x);
+        fmac_bcast<4 * Q + 2>(t2, c[S], x);
+        fmac_bcast<4 * Q + 3>(t3, c[S], x);
+    }
+    // k-steps 4S .. 4S+3 (the last group holds k-step 24 only)
+    template <int S>
+    RMH_DEV void group(const double (&v)[28])
+    {
+        step<S, 0>(v[4 * S]);
+        if (4 * S + 1 < kTailS) {
+            step<S, 1>(v[4 * S + 1]);
+            step<S, 2>(v[4 * S + 2]);
+            step<S, 3>(v[4 * S + 3]);
         }
     }
-    RMH_DEV void fmas(int chunk, const double (&v)[28])
-    {
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const double x = v[5 * chunk + q];
-            t0 = fma_(a[q].x, x, t0);
-            t1 = fma_(a[q].y, x, t1);
-            t2 = fma_(b[q].x, x, t2);
-            t3 = fma_(b[q].y, x, t3);
-        }
-    }
-    RMH_DEV double finish(int g)
-    {
-        return sum4_scatter(t0, t1, t2, t3);
-    }
+    // row g of the result on lane group g
+    RMH_DEV double finish() { return sum4_scatter(t0, t1, t2, t3); }
 };
+
+RMH_DEV double tail_rows(const double *lt, int g, int cl, const double (&v)[28])
+{
+    TailAcc tl;
+#pragma unroll
+    for (int S = 0; S < kTailGroups; ++S) tl.load(lt, g, cl, S);
+    tl.group<0>(v);
+    tl.group<1>(v);
+    tl.group<2>(v);
+    tl.group<3>(v);
+    tl.group<4>(v);
+    tl.group<5>(v);
+    tl.group<6>(v);
+    return tl.finish();
+}
 
 // log N(theta | mu, C) from y = theta - mu for d = 97..100: |W y|^2 with row tiles 0..5 on the
 // matrix core (two in flight) and rows 96..99 on the VALU
 RMH_DEV double gauss_loglik(const double *Wimg, const double *Wt, const GaussArgs &m, int lane, int g,
-                        const double (&y)[28])
+                            int cl, const double (&y)[28])
 {
     using T = Tile<7>;
     constexpr int NF = 6;
@@ -364,7 +374,7 @@ RMH_DEV double gauss_loglik(const double *Wimg, const double *Wt, const GaussArg
     // (chunking this tail between the MFMAs as in the first product was measured twice --
     // inside the last pair of row tiles: 37.5 -> 42.4 ms; one chunk per pair: 59 ms -- the
     // extra live registers spill at the 256-register cap of two waves per SIMD)
-    const double ut = tail_rows(Wt, g, y);
+    const double ut = tail_rows(Wt, g, cl, y);
     uu += ut * ut;
     uu = sum4(uu);
     return -0.5 * ((uu + m.dlog2pi) + m.logdetC);
@@ -410,7 +420,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         double y0[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) y0[s] = th[s] - mu[4 * s + g];
-        double parts0[2] = {0.0, gauss_loglik(Wimg, Wt, m, lane, g, y0)};
+        double parts0[2] = {0.0, gauss_loglik(Wimg, Wt, m, lane, g, cl, y0)};
         pt.sL = parts0[1];
         lp = pt.tempered(parts0);
     }
@@ -435,14 +445,23 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
             acc[i].w = ADAPT ? 0.0 : th[4 * i + 3];
         }
         TailAcc tl;
+        tl.load(Lt, g, cl, 0);
 #pragma unroll
-        for (int s = 0; s < 4 * NF; ++s) {
-            if (s % 5 == 0) tl.load(Lt, g, s / 5);          // chunk s/5: reads now ...
+        for (int sg = 0; sg < NF; ++sg) { // group sg of four k-steps: its MFMAs, then its tail FMAs
+            tl.load(Lt, g, cl, sg + 1);   // next group's entry: the read is covered by the MFMAs
 #pragma unroll
-            for (int i = s / 4; i < NF; ++i) acc[i] = mfma(Limg[T::lo(i, s) * 64 + lane], xi[s], acc[i]);
-            if (s % 5 == 4) tl.fmas(s / 5, xi);             // ... FMAs five k-steps of MFMAs later
+            for (int s = 4 * sg; s < 4 * sg + 4; ++s) {
+#pragma unroll
+                for (int i = sg; i < NF; ++i) acc[i] = mfma(Limg[T::lo(i, s) * 64 + lane], xi[s], acc[i]);
+            }
+            if (sg == 0) tl.group<0>(xi);
+            if (sg == 1) tl.group<1>(xi);
+            if (sg == 2) tl.group<2>(xi);
+            if (sg == 3) tl.group<3>(xi);
+            if (sg == 4) tl.group<4>(xi);
+            if (sg == 5) tl.group<5>(xi);
         }
-        tl.fmas(4, xi);                                     // chunk 4 (k-steps 20..24) was loaded at s = 20
+        tl.group<6>(xi);                  // k-step 24
         double thp[S];
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
@@ -454,9 +473,9 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         if (ADAPT) {
 #pragma unroll
             for (int s = 0; s < 4 * NF; ++s) thp[s] = th[s] + ad.scale * thp[s];
-            thp[24] = th[24] + ad.scale * tl.finish(g);
+            thp[24] = th[24] + ad.scale * tl.finish();
         } else {
-            thp[24] = th[24] + tl.finish(g);
+            thp[24] = th[24] + tl.finish();
         }
         thp[25] = th[25];
         thp[26] = th[26];
@@ -465,7 +484,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         double y[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) y[s] = thp[s] - mu[4 * s + g];
-        double parts[2] = {0.0, gauss_loglik(Wimg, Wt, m, lane, g, y)};
+        double parts[2] = {0.0, gauss_loglik(Wimg, Wt, m, lane, g, cl, y)};
         const double lpp = PT ? pt.tempered(parts) : combine_post(0.0, parts[1]);
         const double u = T::accept_uniform(rng, g, cl);
         bool acc_ok = mh_accept(lpp, lp, 0.0, u);

@@ -153,6 +153,39 @@ struct Tile {
         }
     }
 
+    // The same stream for a dimension known at compile time to need exactly MW words per
+    // sub-stream and to be <= DMAX (8 (MW-1) < d <= min(8 MW, DMAX)): no wave-uniform word and
+    // k-step predicates (in the generic version they live in spilled SGPRs: ~85 v_readlane and
+    // two v_cndmask per normal and iteration for d = 100), a select only on the last two k-steps,
+    // and no evaluation at all for a k-step whose coordinates are all >= DMAX (its half word is
+    // still drawn with its word).
+    template <int MW, int DMAX>
+    static RMH_DEV void normals_fixed(Xo &rng, int d, int g, const double *tab, double (&xi)[S])
+    {
+        static_assert(2 * MW <= S && DMAX <= 8 * MW && DMAX > 8 * (MW - 1), "word count of the dimension");
+#pragma unroll
+        for (int s = 0; s < S; ++s) xi[s] = 0.0;
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            // One word (two normals) per basic block.  Straight-line code lets the scheduler batch
+            // the table reads of all 25 normals and spill their coefficients (105 scratch round
+            // trips per iteration); an opaque always-taken scalar branch costs two SALU instructions.
+            int go;
+            asm volatile("s_mov_b32 %0, 1" : "=s"(go));
+            if (go) {
+                const uint64_t w = xo_next(rng);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int s = 2 * m + k;
+                    const uint32_t h = k ? (uint32_t)w : (uint32_t)(w >> 32);
+                    if (4 * s >= DMAX) continue;
+                    if (m < MW - 1) xi[s] = normal_from_half(h, tab);
+                    else xi[s] = (4 * s + g < d) ? normal_from_half(h, tab) : 0.0;
+                }
+            }
+        }
+    }
+
     // the accept uniform: one word of sub-stream 0 (lanes g == 0), broadcast to
     // the chain's four lanes
     static RMH_DEV double accept_uniform(Xo &rng, int g, int cl)

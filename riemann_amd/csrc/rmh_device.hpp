@@ -318,6 +318,17 @@ RMH_DEV double sum4_scatter(double t0, double t1, double t2, double t3)
     return r.a + r.b;
 }
 
+// all-gather over the chain's four lanes: o[r] = the value row r holds, on all four lanes
+RMH_DEV void gather4(double x, double (&o)[4])
+{
+    const RowPair p = swap16(x, x);            // a = {x0, x0, x2, x2}, b = {x1, x1, x3, x3}
+    const RowPair e = swap32(p.a, p.a), f = swap32(p.b, p.b);
+    o[0] = e.a;
+    o[1] = f.a;
+    o[2] = e.b;
+    o[3] = f.b;
+}
+
 // the value of row 0 (lane cl) on all four lanes of the chain
 RMH_DEV double bcast_row0(double x)
 {

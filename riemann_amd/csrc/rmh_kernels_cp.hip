@@ -74,15 +74,27 @@ struct CpModel {
         return logP;
     }
 
-    // predict (:181) for one datum, valid when cpx is sorted (prior finite)
+    // predict (:181) for one datum, valid when cpx is sorted (prior finite): a chain of
+    // v = (cpx[j] < x) ? cpv[j+1] : v.  Written as C++ selects over the register array, LLVM turns
+    // it into a select of ADDRESSES plus one scratch load per datum (23.2 ms for cfg5); with opaque
+    // copies inside the conditional operands every comparison became a branch (22.5 ms).  The
+    // compare and the two conditional moves are therefore spelled out.
     static RMH_DEV double predict_sorted(const double (&th)[D], double x)
     {
-        // reg(): seen as plain array reads, LLVM rewrites the select chain into a
-        // select of ADDRESSES plus one scratch load per datum
-        double v = reg(th[KC]);
+        uint64_t v = (uint64_t)__double_as_longlong(th[KC]);
+        uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+        // one asm per changepoint, so that the lane mask's two wait states between its VALU write
+        // and its VALU read are there by construction (the compiler pads such pairs itself but
+        // does not look inside asm, and it reorders separate asm statements)
 #pragma unroll
-        for (int j = 0; j < KC; ++j) v = (th[j] < x) ? reg(th[KC + 1 + j]) : v;
-        return v;
+        for (int j = 0; j < KC; ++j) {
+            const uint64_t a = (uint64_t)__double_as_longlong(th[KC + 1 + j]);
+            asm("v_cmp_lt_f64 vcc, %2, %3\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 %1, %1, %5, vcc"
+                : "+v"(lo), "+v"(hi)
+                : "v"(th[j]), "v"(x), "v"((uint32_t)a), "v"((uint32_t)(a >> 32))
+                : "vcc");
+        }
+        return __longlong_as_double((long long)((uint64_t)lo | ((uint64_t)hi << 32)));
     }
 
     // numpy searchsorted(cpx, x) side='left' as a bisection with static
@@ -155,7 +167,13 @@ struct CpPolicy {
         const int cl = lane & 15, g = lane >> 4;
         double full[D];
 #pragma unroll
-        for (int j = 0; j < D; ++j) full[j] = __shfl(th[j >> 2], cl + 16 * (j & 3));
+        for (int q = 0; q < (D + 3) / 4; ++q) {
+            double o[4];
+            gather4(th[q], o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * q + r < D) full[4 * q + r] = o[r];
+        }
         const double logP = CM::log_prior(m, full, g);
         double logL = -__builtin_huge_val();
         // the sorted-cpx likelihood is valid wherever the prior is finite; elsewhere the
@@ -233,11 +251,12 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs
         // theta' = theta + scale L xi  (randomwalk.py:26) on the matrix core, in the
         // 4-lanes-per-chain tile; then the chain's lanes exchange their quarters
         double xi[S];
-        T::normals(rng, ch.M, D, g, tab, xi);
-        double ublk = 0.0;
+        T::template normals_fixed<(D + 7) / 8, D>(rng, D, g, tab, xi);   // D is a compile-time constant
+        double ublk = 0.0, ub[4] = {0.0, 0.0, 0.0, 0.0};
         if (BLOCK) {
             ublk = u01(xo_next(rng));
-            const double u0 = __shfl(ublk, 16 + cl), u1 = __shfl(ublk, 32 + cl), u2 = __shfl(ublk, 48 + cl);
+            gather4(ublk, ub);
+            const double u0 = ub[1], u1 = ub[2], u2 = ub[3];
             int pk = -1;
             if (pr.nblk > 2 && u2 < pr.blk_p[2]) pk = 2;
             if (pr.nblk > 1 && u1 < pr.blk_p[1]) pk = 1;
@@ -259,7 +278,13 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs
         double loc[S], thp[D];
         T::unpack(acc, loc);
 #pragma unroll
-        for (int j = 0; j < D; ++j) thp[j] = __shfl(loc[j >> 2], cl + 16 * (j & 3));
+        for (int q = 0; q < (D + 3) / 4; ++q) { // row swaps (VALU), not ds_bpermute: rmh_device.hpp
+            double o[4];
+            gather4(loc[q], o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * q + r < D) thp[4 * q + r] = o[r];
+        }
 
         const double logP = M::log_prior(m, thp, g);
         double lpp = -__builtin_huge_val();
@@ -268,7 +293,7 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs
             const double logL = M::template log_lik<true>(xy, m, thp, g);
             lpp = combine_post(logP, logL); // model.py:49-55
         }
-        const double u = BLOCK ? __shfl(ublk, cl) : T::accept_uniform(rng, g, cl);
+        const double u = BLOCK ? ub[0] : T::accept_uniform(rng, g, cl);
         const bool ok = mh_accept(lpp, lp, 0.0, u);
         if (ok) {
 #pragma unroll
@@ -516,8 +541,11 @@ __global__ void __launch_bounds__(256) k_cprj_run(CpRjArgs m, ChainArgs ch, RunA
             if (8 * mm + 4 + g < Dn) xw[8 * mm + 4 + g] = zl;
         }
         const double w1 = u01(xo_next(rng)), w2 = u01(xo_next(rng));
-        const double uacc = __shfl(w1, cl), U1 = __shfl(w1, 16 + cl), U2 = __shfl(w1, 32 + cl), U3 = __shfl(w1, 48 + cl);
-        const double U4 = __shfl(w2, cl), us = __shfl(w2, 16 + cl), uu = __shfl(w2, 32 + cl), un = __shfl(w2, 48 + cl);
+        double g1[4], g2[4];
+        gather4(w1, g1);
+        gather4(w2, g2);
+        const double uacc = g1[0], U1 = g1[1], U2 = g1[2], U3 = g1[3];
+        const double U4 = g2[0], us = g2[1], uu = g2[2], un = g2[3];
         __builtin_amdgcn_wave_barrier(); // the wave's LDS writes above are read below (same wave: in order)
 
         typename R::State tp = th;

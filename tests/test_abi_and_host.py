@@ -111,3 +111,30 @@ def test_model_base_log_posterior_guard():
         assert m(np.array([1.0, bad])) == -np.inf
     out = m.log_posterior(np.array([[1.0, 2.0], [np.inf, 0.0], [0.0, np.nan]]))
     np.testing.assert_array_equal(out, [3.0, -np.inf, -np.inf])
+
+
+def test_dpp_hazard_scanner_and_built_kernels():
+    """The hand-written v_fmac_f64_dpp of the tail rows (rmh_run.hpp) must not read a VGPR through
+    DPP within two wait states of a VALU write; the compiler does not check inside inline asm.
+    Compiles the Gaussian translation unit to assembly (no GPU needed) and scans it."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "check_dpp_hazards", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                          "tools", "check_dpp_hazards.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    fake = """
+	v_mov_b64_e32 v[10:11], v[2:3]
+	v_fmac_f64_dpp v[4:5], v[10:11], v[6:7] row_newbcast:3 row_mask:0xf bank_mask:0xf
+	ds_read_b64 v[20:21], v9
+	s_nop 1
+	v_fmac_f64_dpp v[4:5], v[20:21], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf
+	v_add_f64 v[30:31], v[0:1], v[2:3]
+	s_nop 1
+	v_fmac_f64_dpp v[4:5], v[30:31], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf
+"""
+    total, bad = chk.scan(fake)
+    assert total == 3 and len(bad) == 1 and "v_mov_b64" in bad[0]
+    total, bad = chk.main()
+    assert total >= 600 and not bad, bad

@@ -198,7 +198,12 @@ static hipError_t launch_rw_plain(rmh_model *m, rmh_proposal *p, const ChainArgs
 {
     RwArgs ra{p->d_Ltiles, nullptr, 0.0};
     switch (m->kind) {
-    case kGauss: return launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
+    case kGauss:
+        if (m->ga.Wtail && p->d_Ltail && !getenv("RMH_NO_TAIL")) { // d = 97..100: rmh_run.hpp, k_run_rw_tail
+            ra.Ltail = p->d_Ltail;
+            return launch_gauss_rw_tail(m->ga, ra, c, r, adapt, g_stream);
+        }
+        return launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
     case kMixture: return launch_mix_rw(m->NT, m->ma, ra, c, r, adapt, g_stream);
     case kLogReg: return launch_logreg_rw(m->NT, m->la, ra, c, r, adapt, g_stream);
     case kChangepoint: return launch_cp_generic(m->k, m->ca, ra, c, r, adapt ? 1 : 0, g_stream);

@@ -128,3 +128,44 @@ def test_pooled_covariance_adaptation_finds_the_target_covariance(target):
     assert np.abs(est - Ct).max() < 0.02 * np.abs(Ct).max()
     np.testing.assert_allclose(p._SX / (100 * N), mu, atol=0.02)
     moments_ok(s.current_state()[0], mu, Ct)
+
+
+@pytest.mark.parametrize("kind", ["rw", "adapt_rw", "pt"])
+def test_cfg2_size_target_is_invariant(kind):
+    """The same property at the headline shape (d = 100, 65 536 chains): the kernels that run
+    there (four tail rows on the VALU through DPP row broadcasts, row-swap reductions, the
+    fixed-length stream) differ from the generic ones the d = 20 cases above exercise."""
+    import riemann_amd as ra
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import AdaptScaleRandomWalk, MetropolisRandomWalk
+    from riemann_amd.samplers import PTSampler
+    d = 100
+    g = np.random.default_rng(2024)
+    A = g.standard_normal((d, d))
+    Ct = A @ A.T / d + 0.3 * np.eye(d)
+    mu = g.standard_normal(d)
+    Lt = np.linalg.cholesky(Ct)
+    m = MultiGaussianDist(mu, Ct)
+    Cp = (2.38 ** 2 / d) * Ct
+    if kind == "pt":    # every rung started from ITS tempered target, as in the d = 20 case
+        K, Ne = 4, N // 4
+        betas = 0.8 ** np.arange(K)
+        pt = PTSampler(m, MetropolisRandomWalk(Cp), np.tile(mu, (Ne, 1)), betas=betas, Pswap=0.3, seed=11)
+        slots = np.empty((pt._S, d))
+        for i, b in enumerate(betas):
+            slots[pt._idx[:, i]] = mu + g.standard_normal((Ne, d)) @ Lt.T / np.sqrt(b)
+        from riemann_amd import _lib
+        _lib.call("rmh_state_set_theta", pt._state, slots)
+        pt.run(40, Nburn=40)
+        assert (pt._chain_codes == 3).mean() > 0.005
+        for i, b in enumerate(betas):
+            th, _ = pt.samplers[i].current_state()
+            moments_ok(th, mu, Ct / b)
+        return
+    p = MetropolisRandomWalk(Cp) if kind == "rw" else AdaptScaleRandomWalk(Cp)
+    th0 = mu + g.standard_normal((N, d)) @ Lt.T
+    s = ra.Sampler(m, p, th0, seed=13)
+    s.run(60, record=False)
+    th, lp = s.current_state()
+    moments_ok(th, mu, Ct)
+    np.testing.assert_allclose(lp, m.log_posterior(th), rtol=1e-9)

@@ -24,6 +24,21 @@ RMH_DEV double reg(double x)
     return x;
 }
 
+// (lo, hi) <- (a < x) ? y : (lo, hi) on the two halves of a double, spelled out: as a C++ select
+// over a register array LLVM turns a chain of these into a select of ADDRESSES plus one scratch
+// load per datum (cfg5: 23.2 ms), and with opaque copies in the conditional operands every
+// comparison becomes a branch (22.5 ms; this form: 21.6 ms).  One asm per comparison, so that the
+// two wait states a VALU-written lane mask needs before a VALU read are there by construction
+// (the compiler pads such pairs itself but does not look inside asm).
+RMH_DEV void sel_lt(uint32_t &lo, uint32_t &hi, double a, double x, double y)
+{
+    const uint64_t u = (uint64_t)__double_as_longlong(y);
+    asm("v_cmp_lt_f64 vcc, %2, %3\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 %1, %1, %5, vcc"
+        : "+v"(lo), "+v"(hi)
+        : "v"(a), "v"(x), "v"((uint32_t)u), "v"((uint32_t)(u >> 32))
+        : "vcc");
+}
+
 template <int N>
 RMH_DEV double pick(const double (&a)[N], int base, int g)
 {
@@ -75,25 +90,13 @@ struct CpModel {
     }
 
     // predict (:181) for one datum, valid when cpx is sorted (prior finite): a chain of
-    // v = (cpx[j] < x) ? cpv[j+1] : v.  Written as C++ selects over the register array, LLVM turns
-    // it into a select of ADDRESSES plus one scratch load per datum (23.2 ms for cfg5); with opaque
-    // copies inside the conditional operands every comparison became a branch (22.5 ms).  The
-    // compare and the two conditional moves are therefore spelled out.
+    // v = (cpx[j] < x) ? cpv[j+1] : v  (sel_lt above)
     static RMH_DEV double predict_sorted(const double (&th)[D], double x)
     {
-        uint64_t v = (uint64_t)__double_as_longlong(th[KC]);
+        const uint64_t v = (uint64_t)__double_as_longlong(th[KC]);
         uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-        // one asm per changepoint, so that the lane mask's two wait states between its VALU write
-        // and its VALU read are there by construction (the compiler pads such pairs itself but
-        // does not look inside asm, and it reorders separate asm statements)
 #pragma unroll
-        for (int j = 0; j < KC; ++j) {
-            const uint64_t a = (uint64_t)__double_as_longlong(th[KC + 1 + j]);
-            asm("v_cmp_lt_f64 vcc, %2, %3\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 %1, %1, %5, vcc"
-                : "+v"(lo), "+v"(hi)
-                : "v"(th[j]), "v"(x), "v"((uint32_t)a), "v"((uint32_t)(a >> 32))
-                : "vcc");
-        }
+        for (int j = 0; j < KC; ++j) sel_lt(lo, hi, th[j], x, th[KC + 1 + j]);
         return __longlong_as_double((long long)((uint64_t)lo | ((uint64_t)hi << 32)));
     }
 
@@ -440,9 +443,11 @@ struct CpRj {
             const double x = xy[i], y = xy[b.n + i];
             double v;
             if (SORTED) { // cpx sorted (finite prior), +inf beyond k: cpv[#{cpx < x}]
-                v = reg(s.cpv[0]);
+                const uint64_t v0 = (uint64_t)__double_as_longlong(s.cpv[0]);
+                uint32_t lo = (uint32_t)v0, hi = (uint32_t)(v0 >> 32);
 #pragma unroll
-                for (int j = 0; j < KD; ++j) v = (s.cpx[j] < x) ? reg(s.cpv[j + 1]) : v;
+                for (int j = 0; j < KD; ++j) sel_lt(lo, hi, s.cpx[j], x, s.cpv[j + 1]);
+                v = __longlong_as_double((long long)((uint64_t)lo | ((uint64_t)hi << 32)));
             } else { // numpy searchsorted on the first k entries, any order
                 int lo = 0, hi = s.k;
 #pragma unroll

@@ -286,18 +286,20 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
 // With 16-row tiles a 100-dimensional triangular product spends 25 of its 109 MFMAs on the
 // seventh row tile, which holds 4 real rows.  v_mfma_f64 and the VALU share the FP64 units on
 // this chip (rmh_run.hpp header), so those 4 rows are cheaper as plain FMAs: every lane forms
-// the partial dot products of rows 96..99 over its own 25 coordinates (row coefficients from
-// LDS, [s][g][r] so that one ds_read_b128 pair serves four FMAs), the chain's four lanes add
-// them up, and lane group g keeps row 96+g -- exactly the register the MFMA would have written
-// (tile 6, register 0).  1600 MFMA cycles become ~540 VALU cycles per product.
-// Plain MetropolisRandomWalk on MultiGaussianDist only; same results as k_run_rw up to the
-// summation order inside those four rows.
+// the partial dot products of rows 96..99 over its own 25 coordinates, the chain's four lanes
+// add them up (sum4_scatter), and lane group g keeps row 96+g -- exactly the register the MFMA
+// would have written (tile 6, register 0).  1600 MFMA cycles become ~440 VALU cycles per product.
+// MetropolisRandomWalk on MultiGaussianDist: plain, with the per-chain adapted scale (ADAPT) or
+// within parallel tempering (PT); same results as k_run_rw up to the summation order inside
+// those four rows.
 // Coefficient layout in LDS: for each group S of four k-steps and lane group g one 16-double row,
 // entry 4 q + r = row 96+r, column 4 (4S+q) + g.  A lane reads ONE entry per group (a conflict-free
 // ds_read_b64 for the wavefront) and the FMAs take the entry they need from the lane that holds
 // it with the DPP row broadcast of v_fmac_f64 (row_newbcast: lane n of the own 16-lane row).
 // The 16 lanes of a row share all their coefficients, so reading four per lane and k-step
 // (2 ds_read_b128, the first version) moved 16x the bytes: those reads cost 2.0 of 34.8 ms.
+// The DPP source must not have been written by the VALU in the two preceding wait states; the
+// compiler does not see inside the asm, tools/check_dpp_hazards.py (a CPU test) checks the build.
 constexpr int kTailS = 25, kTailGroups = 7, kTailDoubles = kTailGroups * 64;
 
 // t <- fma(row-broadcast of lane N of c, x, t)
@@ -371,9 +373,9 @@ RMH_DEV double gauss_loglik(const double *Wimg, const double *Wt, const GaussArg
         uu += a0.x * a0.x + a0.y * a0.y + a0.z * a0.z + a0.w * a0.w;
         uu += a1.x * a1.x + a1.y * a1.y + a1.z * a1.z + a1.w * a1.w;
     }
-    // (chunking this tail between the MFMAs as in the first product was measured twice --
-    // inside the last pair of row tiles: 37.5 -> 42.4 ms; one chunk per pair: 59 ms -- the
-    // extra live registers spill at the 256-register cap of two waves per SIMD)
+    // (with the first tail version -- four coefficients per lane and k-step from LDS -- spreading
+    // this tail between the MFMAs spilled at the 256-register cap, 37.5 -> 42..59 ms; with one
+    // coefficient per four k-steps there is no read latency left worth hiding)
     const double ut = tail_rows(Wt, g, cl, y);
     uu += ut * ut;
     uu = sum4(uu);

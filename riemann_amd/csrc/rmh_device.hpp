@@ -229,7 +229,7 @@ RMH_DEV void logistic_terms(double eta, const double *tab, double &lse, double &
 // normal against 42; on this chip f64 MFMA and VALU share the FP64 units, so every VALU cycle
 // counts -- cfg2 38.1 -> 35.4 ms).
 // The table (tools/gen_icdf_table.py, worst error 2.1e-16 relative; rows 0..31 of it) is staged
-// in LDS with a 96-byte cell stride: six ds_read_b128 per normal.
+// in LDS with a 96-byte cell stride: five ds_read_b128 and one ds_read_b64 per normal.
 // Rows are 16 B longer than their 8 cells so that the cells of rows r and r+1
 // (3/4 of all draws) fall on disjoint LDS banks.
 constexpr int kIcdfRows = 32, kIcdfSub = 8, kIcdfNC = 11, kIcdfStride = 12;
@@ -241,33 +241,53 @@ RMH_DEV void icdf_stage(double *lds_tab, const double *glb_tab)
     for (int i = threadIdx.x; i < kIcdfDoubles; i += blockDim.x) lds_tab[i] = glb_tab[i];
 }
 
+// N normals in lockstep (the halves of one or two stream words): all cells' table reads first,
+// then the N Horner chains alternating.  Evaluated one after the other (what the compiler makes
+// of separate normal_from_half calls) every normal exposes its LDS latency and ten dependent
+// fma latencies.  Same operations per normal, in the same order: the same bits.
+template <int N>
+RMH_DEV void normals_lockstep(const uint32_t (&h)[N], const double *tab, double (&z)[N])
+{
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    double t[N];
+    const d2_t *c[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t q = h[i] | 1u;
+        const int r = __builtin_clz(q);
+        const uint32_t Nn = q << r;
+        const int j = (int)(Nn >> 28) & 7;
+        // t = 2 v - 3 with v = 1 + m27 2^-27, i.e. m27 2^-26 - 1: exact either way, the same bits
+        t[i] = fma_((double)((Nn >> 1) & 0x7FFFFFFu), 0x1p-26, -1.0);
+        c[i] = static_cast<const d2_t *>(__builtin_assume_aligned(tab + r * kIcdfRowStride + j * kIcdfStride, 16));
+    }
+    // (the leading coefficient as ONE double: read as half of a 16-byte pair its unused upper
+    // registers get reused at once, and the next read then has to wait for this one)
+#pragma unroll
+    for (int i = 0; i < N; ++i) z[i] = reinterpret_cast<const double *>(c[i])[10];
+    d2_t a[N][5];
+#pragma unroll
+    for (int k = 4; k >= 0; --k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) a[i][k] = c[i][k];
+#pragma unroll
+    for (int k = 4; k >= 0; --k) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) z[i] = fma_(z[i], t[i], a[i][k].y);
+#pragma unroll
+        for (int i = 0; i < N; ++i) z[i] = fma_(z[i], t[i], a[i][k].x);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        z[i] = __longlong_as_double(__double_as_longlong(z[i]) ^ ((long long)(h[i] & 1u) << 63));
+}
+
 RMH_DEV double normal_from_half(uint32_t h, const double *tab)
 {
-    const uint32_t q = h | 1u;
-    const int r = __builtin_clz(q);
-    const uint32_t N = q << r;                          // bit 31 is set: no need to or it in
-    const int j = (int)(N >> 28) & 7;
-    const uint32_t m27 = (N >> 1) & 0x7FFFFFFu;
-    // t = 2 v - 3 with v = 1 + m27 2^-27, i.e. m27 2^-26 - 1: exact either way, so the same bits
-    // as fma(2, v, -3) on the assembled double -- and one conversion instead of three bit operations
-    const double t = fma_((double)m27, 0x1p-26, -1.0);
-    // 16-byte aligned by construction (table base, 784-B rows, 96-B cells): six ds_read_b128
-    typedef double d2_t __attribute__((ext_vector_type(2)));
-    const d2_t *c = static_cast<const d2_t *>(
-        __builtin_assume_aligned(tab + r * kIcdfRowStride + j * kIcdfStride, 16));
-    const d2_t c01 = c[0], c23 = c[1], c45 = c[2], c67 = c[3], c89 = c[4], cA = c[5];
-    double z = cA.x;
-    z = fma_(z, t, c89.y);
-    z = fma_(z, t, c89.x);
-    z = fma_(z, t, c67.y);
-    z = fma_(z, t, c67.x);
-    z = fma_(z, t, c45.y);
-    z = fma_(z, t, c45.x);
-    z = fma_(z, t, c23.y);
-    z = fma_(z, t, c23.x);
-    z = fma_(z, t, c01.y);
-    z = fma_(z, t, c01.x);
-    return __longlong_as_double(__double_as_longlong(z) ^ ((long long)(h & 1u) << 63));
+    const uint32_t hh[1] = {h};
+    double z[1];
+    normals_lockstep<1>(hh, tab, z);
+    return z[0];
 }
 
 constexpr double k2m53 = 0x1p-53;

@@ -207,7 +207,10 @@ __global__ void __launch_bounds__(256) k_big_rw(GaussArgs m, RwArgs pr, ChainArg
             double *Yw = Y + jw * ystride;
             for (int mm = 0; mm < ch.M; ++mm) { // Y[s] is coordinate 4s + g: halves of word mm -> s = 2mm, 2mm+1
                 const uint64_t wd = xo_next(rng);
-                const double zh = normal_from_half((uint32_t)(wd >> 32), tab), zl = normal_from_half((uint32_t)wd, tab);
+                const uint32_t hw[2] = {(uint32_t)(wd >> 32), (uint32_t)wd};
+            double zw[2];
+            normals_lockstep<2>(hw, tab, zw);
+            const double zh = zw[0], zl = zw[1];
                 Yw[(2 * mm) * 64 + lane] = (8 * mm + g < ch.d) ? zh : 0.0;
                 if (2 * mm + 1 < 4 * NT) Yw[(2 * mm + 1) * 64 + lane] = (8 * mm + 4 + g < ch.d) ? zl : 0.0;
             }

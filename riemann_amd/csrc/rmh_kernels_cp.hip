@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs
         // theta' = theta + scale L xi  (randomwalk.py:26) on the matrix core, in the
         // 4-lanes-per-chain tile; then the chain's lanes exchange their quarters
         double xi[S];
-        T::template normals_fixed<(D + 7) / 8, D>(rng, D, g, tab, xi);   // D is a compile-time constant
+        T::template normals_fixed<(D + 7) / 8, D, 1>(rng, D, g, tab, xi);   // D is a compile-time constant
         double ublk = 0.0, ub[4] = {0.0, 0.0, 0.0, 0.0};
         if (BLOCK) {
             ublk = u01(xo_next(rng));
@@ -541,7 +541,10 @@ __global__ void __launch_bounds__(256) k_cprj_run(CpRjArgs m, ChainArgs ch, RunA
         // coordinates 8 mm + g and 8 mm + 4 + g
         for (int mm = 0; mm < (Dn + 7) / 8; ++mm) { // the normals cover the 2 KM + 2 padded coordinates
             const uint64_t w = xo_next(rng);
-            const double zh = normal_from_half((uint32_t)(w >> 32), tab), zl = normal_from_half((uint32_t)w, tab);
+            const uint32_t hw[2] = {(uint32_t)(w >> 32), (uint32_t)w};
+            double zw[2];
+            normals_lockstep<2>(hw, tab, zw);
+            const double zh = zw[0], zl = zw[1];
             if (8 * mm + g < Dn) xw[8 * mm + g] = zh;
             if (8 * mm + 4 + g < Dn) xw[8 * mm + 4 + g] = zl;
         }

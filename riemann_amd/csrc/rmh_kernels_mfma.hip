@@ -338,7 +338,10 @@ __global__ void k_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const doub
     for (int t = 0; t < T; ++t) {
         for (int m = 0; m < Mw; ++m) {
             const uint64_t w = xo_next(x);
-            const double zh = normal_from_half((uint32_t)(w >> 32), tab), zl = normal_from_half((uint32_t)w, tab);
+            const uint32_t hw[2] = {(uint32_t)(w >> 32), (uint32_t)w};
+            double zw[2];
+            normals_lockstep<2>(hw, tab, zw);
+            const double zh = zw[0], zl = zw[1];
             if (8 * m + g < d) xi[((int64_t)t * ld + c) * d + 8 * m + g] = zh;
             if (8 * m + 4 + g < d) xi[((int64_t)t * ld + c) * d + 8 * m + 4 + g] = zl;
         }

@@ -140,11 +140,19 @@ struct Tile {
                     w[k] = 0;
                     if (m0 / 2 + k < Mw) w[k] = xo_next(rng);
                 }
+                // four normals in lockstep; the small tiles run many waves per SIMD on few
+                // registers and take them in pairs (d = 16: 3.62 ms per 1000 iterations against 3.80)
+                constexpr int LS = (S <= 8) ? 2 : GRP;
 #pragma unroll
-                for (int k = 0; k < GRP; ++k) {
-                    const uint32_t h = (k & 1) ? (uint32_t)w[k / 2] : (uint32_t)(w[k / 2] >> 32);
-                    const double z = normal_from_half(h, tab);
-                    xi[m0 + k] = (4 * (m0 + k) + g < d) ? z : 0.0;
+                for (int k0 = 0; k0 < GRP; k0 += LS) {
+                    uint32_t h[LS];
+                    double z[LS];
+#pragma unroll
+                    for (int k = 0; k < LS; ++k)
+                        h[k] = ((k0 + k) & 1) ? (uint32_t)w[(k0 + k) / 2] : (uint32_t)(w[(k0 + k) / 2] >> 32);
+                    normals_lockstep<LS>(h, tab, z);
+#pragma unroll
+                    for (int k = 0; k < LS; ++k) xi[m0 + k0 + k] = (4 * (m0 + k0 + k) + g < d) ? z[k] : 0.0;
                 }
             } else {
 #pragma unroll
@@ -159,30 +167,51 @@ struct Tile {
     // two v_cndmask per normal and iteration for d = 100), a select only on the last two k-steps,
     // and no evaluation at all for a k-step whose coordinates are all >= DMAX (its half word is
     // still drawn with its word).
-    template <int MW, int DMAX>
+    template <int MW, int DMAX, int WPB = 2>
     static RMH_DEV void normals_fixed(Xo &rng, int d, int g, const double *tab, double (&xi)[S])
     {
         static_assert(2 * MW <= S && DMAX <= 8 * MW && DMAX > 8 * (MW - 1), "word count of the dimension");
 #pragma unroll
         for (int s = 0; s < S; ++s) xi[s] = 0.0;
-#pragma unroll
-        for (int m = 0; m < MW; ++m) {
-            // One word (two normals) per basic block.  Straight-line code lets the scheduler batch
-            // the table reads of all 25 normals and spill their coefficients (105 scratch round
-            // trips per iteration); an opaque always-taken scalar branch costs two SALU instructions.
+        fixed_block<MW, DMAX, WPB, 0>(rng, d, g, tab, xi);
+    }
+
+    // Words M0 .. M0+WPB-1 of the stream (WPB = 2: four normals) in one basic block, evaluated
+    // in lockstep (normals_lockstep), then the following blocks.  Straight-line code over all
+    // words lets the scheduler batch the table reads of all 25 normals and spill their
+    // coefficients (105 scratch round trips per iteration, 210 ms); an opaque always-taken scalar
+    // branch costs two SALU instructions.  Normals per block, cfg2: 1 (evaluated one after the
+    // other) 32.6 ms, 2 in lockstep 32.0 ms, 4 in lockstep 31.8 ms (44 coefficient registers per
+    // normal pair: kernels at four waves per SIMD take WPB = 1).
+    template <int MW, int DMAX, int WPB, int M0>
+    static RMH_DEV void fixed_block(Xo &rng, int d, int g, const double *tab, double (&xi)[S])
+    {
+        if constexpr (M0 < MW) {
+            constexpr int NWD = (MW - M0 < WPB) ? MW - M0 : WPB;       // words of this block
+            constexpr int S0 = 2 * M0;                                                  // its first k-step
+            constexpr int KS = (DMAX + 3) / 4;                  // k-steps that hold coordinates < DMAX
+            constexpr int NS = (KS - S0 < 2 * NWD) ? KS - S0 : 2 * NWD;                 // normals to evaluate
+            constexpr bool LAST = S0 + NS > 2 * MW - 2;         // k-steps 2MW-2.. may hold coordinates >= d
             int go;
             asm volatile("s_mov_b32 %0, 1" : "=s"(go));
             if (go) {
-                const uint64_t w = xo_next(rng);
+                uint32_t h[2 * NWD];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int s = 2 * m + k;
-                    const uint32_t h = k ? (uint32_t)w : (uint32_t)(w >> 32);
-                    if (4 * s >= DMAX) continue;
-                    if (m < MW - 1) xi[s] = normal_from_half(h, tab);
-                    else xi[s] = (4 * s + g < d) ? normal_from_half(h, tab) : 0.0;
+                for (int q = 0; q < NWD; ++q) {
+                    const uint64_t w = xo_next(rng);
+                    h[2 * q] = (uint32_t)(w >> 32);
+                    h[2 * q + 1] = (uint32_t)w;
                 }
+                uint32_t hs[NS];
+                double z[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) hs[i] = h[i];
+                normals_lockstep<NS>(hs, tab, z);
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+                    xi[S0 + i] = (!LAST || S0 + i < 2 * MW - 2 || 4 * (S0 + i) + g < d) ? z[i] : 0.0;
             }
+            fixed_block<MW, DMAX, WPB, M0 + WPB>(rng, d, g, tab, xi);
         }
     }
 

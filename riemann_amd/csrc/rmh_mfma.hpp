@@ -251,6 +251,8 @@ struct Tile {
 
     // history entries hold 4*ks rows (d rounded up to 4): rows 4s..4s+3 are
     // written iff s < ks, a wave-uniform test
+    // KS > 0: ks is that compile-time constant (no test, no branch per row)
+    template <int KS = 0>
     static RMH_DEV void store_rows(double *dst, int64_t ld, int64_t c, int g, int ks,
                                    const double (&th)[S])
     {
@@ -258,7 +260,7 @@ struct Tile {
         const uint32_t voff = (uint32_t)(g * ld + c) * 8u, row = (uint32_t)ld * 32u;
 #pragma unroll
         for (int s = 0; s < S; ++s)
-            if (s < ks) buf_store(r, voff, row * (uint32_t)s, th[s]);
+            if (KS > 0 ? s < KS : s < ks) buf_store(r, voff, row * (uint32_t)s, th[s]);
     }
 };
 

@@ -21,7 +21,7 @@ struct Keep {
     int64_t next, entry;
     RMH_DEV explicit Keep(const RunArgs &run) : next(run.nburn), entry(0) {}
 
-    template <int NT>
+    template <int NT, int KS = 0>   // KS > 0: ch.ks is that constant (Tile::store_rows)
     RMH_DEV void record(const RunArgs &run, const ChainArgs &ch, int64_t e, int64_t c, int g,
                         bool active, const double (&th)[4 * NT], double lp)
     {
@@ -30,7 +30,7 @@ struct Keep {
         const int64_t k = entry++;
         if (!run.h_theta || !active) return;
         double *dst = run.h_theta + k * (int64_t)(4 * ch.ks) * ch.ld;
-        Tile<NT>::store_rows(dst, ch.ld, c, g, ch.ks, th);
+        Tile<NT>::template store_rows<KS>(dst, ch.ld, c, g, KS > 0 ? KS : ch.ks, th);
         if (g == 0) run.h_logpost[k * ch.ld + c] = lp;
     }
 };
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         lp = pt.tempered(parts0);
     }
     Keep keep(run);
-    keep.record<NT>(run, ch, 0, c, g, active, th, lp);
+    keep.record<NT, 25>(run, ch, 0, c, g, active, th, lp);
     AdaptScale ad{0.0, 0.0, 1.0};
     if (ADAPT) ad.load(ch, c);
 
@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         if (PT) code = pt.swap(lane, acc_ok, parts, th, lp);
         if (ADAPT) ad.adapt(acc_ok, ch.adapt_target);
         if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = (uint8_t)code;
-        keep.record<NT>(run, ch, t + 1, c, g, active, th, lp);
+        keep.record<NT, 25>(run, ch, t + 1, c, g, active, th, lp);
     }
     if (active) {
         T::store_state(ch.theta, ch.ld, c, g, th);

@@ -2,21 +2,31 @@
 """Benchmark of the many-chain MH hot path on MI355X (BASELINE.json metric:
 MH chain-iterations/sec aggregate over N chains; ESS/sec).
 
-    python bench.py --gpus 1 --steps K --warmup W [--workload gauss_rw]
+    python bench.py --gpus 1 --steps K --warmup W [--workload logreg_mala]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+    cfg4 (BASELINE.json configs[3]):  ... --nproc-per-node 8 bench.py --gpus 8 --workload logreg_hmc
+    cfg5 (configs[4]):                ... --nproc-per-node 4 bench.py --gpus 4 --workload changepoint_rw
 
 A "step" is one fused ``rmh_run`` launch: ``iters`` MH iterations for every
 chain of this rank, every state recorded into an HBM-resident history
 (the reference records every state, riemann/samplers/sampler.py:69-70).
 Inputs are synthetic (riemann_amd/workloads.py) and resident in HBM before the
 timed region.  Chains shard across ranks by global chain id with no collective
-in the timed region (weak scaling: 65 536 chains per GPU); after it the ranks
-all-gather their final states over RCCL for the pooled diagnostics.
+in the timed region (weak scaling: 65 536 chains per GPU).  The launcher only
+provides RANK / WORLD_SIZE / MASTER_*: nothing of PyTorch is imported -- the
+barrier, the max-over-ranks of the timing and the pooling of the final states
+(one all-gather, one all-reduce of moments) go through the library's own RCCL
+communicator (rmh_comm_*, csrc/rmh_comm.hip), the 128-byte id over a socket
+(riemann_amd.distributed.HostGroup).
 
-Prints ONE JSON line (rank 0).  Default workload = BASELINE.json configs[1].
+Prints ONE JSON line (rank 0).  Default workload = north_star's target, BASELINE.json
+configs[2] (cfg3: logistic regression 10 000 x 100, MALA, 65 536 chains, f64); at one GPU
+the line carries an "also" list with short runs of cfg2, cfg4 (per-GPU share) and cfg5.
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -30,6 +40,7 @@ if ROOT not in sys.path:
 
 FP64_MFMA_PEAK = 78.6e12   # MI355X FP64 matrix = FP64 vector peak, AMD public spec
 HBM_PEAK = 8.0e12          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+WORKLOADS = ["logreg_mala", "gauss_rw", "logreg_hmc", "changepoint_rw", "pt_gauss"]
 
 
 def workload(name, chains):
@@ -57,12 +68,12 @@ def workload(name, chains):
         return dict(model=m, proposal=MALA(eps, m) if L == 1 else VanillaHMC(eps, L, m),
                     theta0=th0, d=d, iters=200 if L == 1 else 100, flops=4 * n * d * L,
                     bytes=2 * 8 * (2 * d + 1) + 8 * (d + 1), bound="mfma",
-                    label=("cfg3: logistic regression 10000x100, MALA" if L == 1 else
-                           "cfg4: logistic regression 10000x100, HMC L=10"),
+                    label=("cfg3: logistic regression 10000x100, MALA, 65536 chains/GPU" if L == 1 else
+                           "cfg4: logistic regression 10000x100, HMC L=10, 65536 chains/GPU"),
                     omodel=lambda o: o.LogReg(X, y, 100.0), oprop=lambda o: o.HMC(eps, L, d),
                     twin=lambda t: ((lambda tm: (tm, t.TwinHMC(eps, L, tm.grad), 300 if L == 1 else 40))
                                     (t.TwinLogReg(X, y, 100.0))),
-                    cpu_sample=(4096, 4) if L == 1 else (2048, 2))
+                    cpu_sample=(8192, 16) if L == 1 else (2048, 4))
     if name == "changepoint_rw":                # configs[4]
         x, y, truth, cdiag = W.changepoint_data()
         k, d = 5, 12
@@ -75,7 +86,7 @@ def workload(name, chains):
                     theta0=th0, d=d, iters=2000, flops=900, bytes=8 * (d + 1), bound="hbm",
                     label="cfg5: changepoint k=5 (n=100), random-walk MH",
                     omodel=lambda o: o.Changepoint(x, y, k, 1.0, 3.0, 5.0, 1.0, 1.0),
-                    oprop=lambda o: o.RandomWalk(np.diag(cdiag), 0.1), cpu_sample=(65536, 400))
+                    oprop=lambda o: o.RandomWalk(np.diag(cdiag), 0.1), cpu_sample=(65536, 1000))
     if name == "pt_gauss":      # PTSampler, default ladder, on the cfg2 target
         d, K = 100, 5
         Ct = W.corr_gauss_cov(d)
@@ -91,16 +102,26 @@ def workload(name, chains):
     raise SystemExit("unknown workload " + name)
 
 
-def measured_traffic(name):
-    """HBM bytes per chain-iteration of the run kernel from the committed PMC
-    passes (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in
-    separate rocprofv3 --pmc runs of this same command, FETCH doubled as the
-    gfx950 note of MI355X_MICROARCH.md prescribes), or None."""
+def measured_profile(name):
+    """Committed PMC measurements of the workload's run kernel (profiles/pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command,
+    FETCH doubled as the gfx950 note of MI355X_MICROARCH.md prescribes), or {}."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)[name]["hbm_bytes_per_chain_iteration"]
+            return json.load(f)[name]
     except Exception:
-        return None
+        return {}
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(w, seed):
@@ -120,6 +141,7 @@ def cpu_baseline(w, seed):
         orc.run_pt(m, p, th, st, T, w["pt"]["betas"], w["pt"]["pswap"], history=False)
         dt = time.perf_counter() - t0
         return {"value": N * K * T / dt, "unit": "chain-iterations/s", "cores": 1, "kind": "port",
+                "cpu": cpu_model(),
                 "sample": "%d ladders x %d temperatures x %d sweeps, oracle/rmh_oracle.c orc_run_pt "
                           "(one thread), %.1f s" % (N, K, T, dt)}
     th = np.ascontiguousarray(w["theta0"][:N]).copy()
@@ -132,6 +154,7 @@ def cpu_baseline(w, seed):
     orc.run(m, p, th, lp, st, T, history=False, nthreads=threads)
     dt = time.perf_counter() - t0
     out = {"value": N * T / dt, "unit": "chain-iterations/s", "cores": threads, "kind": "port",
+           "cpu": cpu_model(),
            "sample": "%d chains x %d iterations of the same workload, oracle/rmh_oracle.c "
                      "(OpenMP over chains), %.1f s" % (N, T, dt)}
     tw = w.get("twin")
@@ -159,46 +182,60 @@ def tau_estimate(w, seed):
     return float(np.max(tau)), float(s._chain_accept.mean())
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="gauss_rw",
-                    choices=["gauss_rw", "logreg_mala", "logreg_hmc", "changepoint_rw", "pt_gauss"])
-    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
-    ap.add_argument("--iters", type=int, default=0, help="MH iterations per step (0 = workload default)")
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ess", action="store_true")
-    ap.add_argument("--no-record", action="store_true", help="do not record the history (diagnostic)")
-    a = ap.parse_args()
+class Ranks(object):
+    """Barrier / max over the ranks: the library's RCCL communicator when it formed, the host
+    socket group otherwise (e.g. several ranks rehearsing on ONE GPU, where RCCL refuses)."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
-        import torch
-        import torch.distributed as dist
-        local = local % max(torch.cuda.device_count(), 1)   # ranks that see one device each
-        torch.cuda.set_device(local)
-        backend = os.environ.get("RMH_BENCH_BACKEND", "nccl")   # "gloo": rehearsal without RCCL
-        if backend == "nccl":
+    def __init__(self):
+        from riemann_amd import _lib
+        from riemann_amd.distributed import HostGroup, comm_init
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.group = HostGroup.from_env() if self.world > 1 else HostGroup(0, 1)
+        self.rccl, self.rccl_error = False, None
+        if os.environ.get("RMH_BENCH_NO_RCCL") != "1":
+            # RCCL prints a version banner on stdout when a communicator forms: keep stdout for
+            # the ONE JSON line (the banner goes to stderr)
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
             try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-            except Exception as e:      # keep the measurement: the timed region has no collective
-                sys.stderr.write("bench: nccl process group failed (%r), using gloo\n" % (e,))
-                backend = "gloo"
-        if backend != "nccl":
-            dist.init_process_group(backend)
-        cdev = "cuda" if backend == "nccl" else None            # where collective buffers live
+                comm_init(self.group)
+                _lib.call("rmh_comm_barrier")          # builds the communicator's channels untimed
+                self.rccl = True
+            except Exception as e:     # keep the measurement: the timed region has no collective
+                self.rccl_error = repr(e)[:300]
+            finally:
+                os.dup2(keep, 1)
+                os.close(keep)
+        ok = self.group.allgather(self.rccl)
+        if not all(ok):                # all or none: a half-formed communicator would hang
+            self.rccl = False
 
+    def barrier(self):
+        from riemann_amd import _lib
+        _lib.call("rmh_synchronize")
+        if self.rccl:
+            _lib.call("rmh_comm_barrier")
+        else:
+            self.group.barrier()
+
+    def max(self, x):
+        from riemann_amd import _lib
+        if self.rccl:
+            b = np.array([float(x)])
+            _lib.call("rmh_comm_allreduce_host", b, 1, 1)
+            return float(b[0])
+        return self.group.max(x)
+
+
+def measure(name, a, ranks, steps, warmup, iters=0, with_cpu=True, with_ess=True, with_pool=True):
+    """Time `steps` fused launches of one workload on this rank's shard; rank 0 gets the result dict."""
     import riemann_amd as ra
     from riemann_amd import _lib
-    _lib.call("rmh_init", local)
-    w = workload(a.workload, a.chains)
-    iters = a.iters or w["iters"]
+    rank, world = ranks.rank, ranks.world
+    w = workload(name, a.chains)
+    iters = iters or w["iters"]
     N, d = w["theta0"].shape
 
     # chains of this rank: global ids [rank*N, (rank+1)*N) -- RNG keyed by global id
@@ -224,24 +261,12 @@ def main():
             _lib.call("rmh_run", w["model"]._h, w["proposal"]._h, s._state, iters, 0, 1,
                       hist if hist else None)
 
-    def barrier():
-        _lib.call("rmh_synchronize")
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
-    if dist is not None:    # first collectives build the RCCL communicator: keep that out of the timing
-        import torch
-        for _ in range(3):
-            dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=cdev), op=dist.ReduceOp.MAX)
-            dist.barrier()
-    barrier()
+    ranks.barrier()
     kernel_ms, step_end = [], []
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
         # HIP events on the library's stream around each launch; reading them
         # waits for the launch, which the next launch on the same stream would do anyway
@@ -249,36 +274,32 @@ def main():
         _lib.call("rmh_last_run_ms", C.byref(ms), None)
         kernel_ms.append(ms.value)
         step_end.append(time.perf_counter())
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    ranks.barrier()
+    dt = ranks.max(time.perf_counter() - t0)
 
-    # pool the final states of all ranks over RCCL (diagnostics only, untimed)
+    # pool the final states of all ranks over RCCL (diagnostics only, untimed): the library's own
+    # communicator, device-resident state blocks -> one ncclAllGather + one ncclAllReduce
     pooled = None
-    if dist is not None:
-        try:
-            from riemann_amd.distributed import pool_samples, pooled_moments
-            th, lp = s.current_state()          # PT: the beta = 1 rung of every ladder
-            allth = pool_samples(th, world * N, device=cdev)        # RCCL all-gather over xGMI
-            mean, cov = pooled_moments(th, device=cdev)             # RCCL all-reduce
-            pooled = {"allgather_bytes_per_rank": int(th.size * 8),
-                      "pooled_chains": int(allth.shape[0]),
-                      "pooled_mean_abs_max": float(np.abs(mean).max()),
-                      "pooled_var_mean": float(np.diag(cov).mean())}
-        except Exception as e:  # never lose the measurement to the diagnostics
-            pooled = {"allgather_error": repr(e)[:200]}
-
+    if with_pool and not pt:
+        if ranks.rccl:
+            try:
+                from riemann_amd.distributed import pool
+                allth, mean, cov, info = pool(s)
+                pooled = dict(info, pooled_mean_abs_max=float(np.abs(mean).max()),
+                              pooled_var_mean=float(np.diag(cov).mean()))
+            except Exception as e:  # never lose the measurement to the diagnostics
+                pooled = {"rccl_ranks": 0, "allgather_error": repr(e)[:300]}
+        else:
+            pooled = {"rccl_ranks": 0, "rccl_error": ranks.rccl_error}
+    if hist:
+        _lib.call("rmh_history_free", hist)
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        del s
+        gc.collect()
+        return None
     if pt:
         N = N * K                # replicas: every one makes a within-chain or a swap move per sweep
-    total_iters = world * N * iters * a.steps
+    total_iters = world * N * iters * steps
     value = total_iters / dt
     kms = float(np.mean(kernel_ms))
     flops = w["flops"] * N * iters
@@ -287,12 +308,11 @@ def main():
         ach, peak, unit = flops / (kms * 1e-3) / 1e12, FP64_MFMA_PEAK / 1e12, "TFLOP/s"
     else:
         ach, peak, unit = bytes_ / (kms * 1e-3) / 1e9, HBM_PEAK / 1e9, "GB/s"
-    tr = measured_traffic(a.workload)
+    prof = measured_profile(name)
+    tr = prof.get("hbm_bytes_per_chain_iteration")
     out = {
-        "metric": "MH chain-iterations/sec", "value": value, "unit": "chain-iterations/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic",
+        "value": value, "unit": "chain-iterations/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3,
         "config": {"workload": w["label"], "chains_per_gpu": N, "dim": d,
                    "iterations_per_step": iters, "recorded": (not a.no_record),
                    "parallelism": "chains sharded by global id, %d rank(s)" % world},
@@ -304,24 +324,88 @@ def main():
                      "flops_per_chain_iteration": w["flops"],
                      "bytes_per_chain_iteration": w["bytes"]},
     }
+    if name == "changepoint_rw" and prof.get("valu_insts_per_wave_iteration"):
+        # the kernel's real bound: VALU issue (one instruction per 4 cycles per SIMD, 16 chains per
+        # wave) at the committed instruction count (profiles/r02_sq_counters.json)
+        vi = prof["valu_insts_per_wave_iteration"]
+        roof = 256 * 4 * 2.4e9 / 4.0 / vi * 16
+        out["roofline"]["valu_issue"] = {"insts_per_wave_iteration": vi, "roof_chain_iterations_per_s": roof,
+                                         "frac": (N * iters / (kms * 1e-3)) / roof}
     if pooled:
         out["pool"] = pooled
-    if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed at N=1 only
+    if with_cpu and world == 1:   # the CPU leg is timed at N=1 only
         out["cpu_baseline"] = cpu_baseline(w, a.seed)
     if pt:
         out["config"]["ladders_per_gpu"] = N // K
         out["config"]["temperatures"] = K
         out["config"]["chain_slots_per_gpu"] = a.chains
-    if not a.no_ess and world == 1 and not pt:
+    if with_ess and world == 1 and not pt:
         try:
             tau, acc = tau_estimate(w, a.seed)
             out["ess"] = {"tau_int_max": tau, "accept_rate": acc, "ess_per_sec": value / tau,
-                          "estimator": "FFT autocorrelation, Sokal window c=5, 256 chains"}
+                          "estimator": "FFT autocorrelation, Sokal window c=5, 256 chains "
+                                       "(riemann_amd/diagnostics.py); parity unpinned: the reference's "
+                                       "emcee.autocorr.integrated_time is not installed here"}
         except Exception as e:
             out["ess"] = {"error": repr(e)[:200]}
-    print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    del s, w
+    gc.collect()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=None, choices=WORKLOADS,
+                    help="default: logreg_mala (cfg3) with cfg2/cfg4/cfg5 alongside in \"also\"")
+    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
+    ap.add_argument("--iters", type=int, default=0, help="MH iterations per step (0 = workload default)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ess", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the short runs of the other configs")
+    ap.add_argument("--no-record", action="store_true", help="do not record the history (diagnostic)")
+    a = ap.parse_args()
+
+    from riemann_amd import _lib
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = C.c_int()
+    _lib.call("rmh_device_count", C.byref(ndev))
+    _lib.call("rmh_init", local % max(ndev.value, 1))   # ranks that see one device each land on it
+    ranks = Ranks()
+    main_wl = a.workload or "logreg_mala"
+    out = measure(main_wl, a, ranks, a.steps, a.warmup, iters=a.iters, with_cpu=not a.no_cpu_baseline,
+                  with_ess=not a.no_ess)
+    also = []
+    if a.workload is None and not a.no_also and ranks.world == 1:
+        # short runs of the other BASELINE configs in the same process: cfg4 and cfg5 are
+        # multi-GPU configurations, measured here as their per-GPU share (65 536 chains)
+        for name, st, wu, it in (("gauss_rw", 3, 1, 0), ("logreg_hmc", 2, 1, 20), ("changepoint_rw", 3, 1, 0)):
+            try:
+                r = measure(name, a, ranks, st, wu, iters=it, with_cpu=not a.no_cpu_baseline,
+                            with_ess=False, with_pool=False)
+                r["workload"] = name
+                also.append(r)
+            except Exception as e:
+                also.append({"workload": name, "error": repr(e)[:300]})
+    if ranks.rank == 0:
+        line = {"metric": "MH chain-iterations/sec", "value": out["value"], "unit": out["unit"],
+                "n_gpus": ranks.world, "steps": out["steps"], "warmup": out["warmup"],
+                "ms_per_step": out["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+        for k in ("config", "roofline", "pool", "cpu_baseline", "ess"):
+            if k in out:
+                line[k] = out[k]
+        if also:
+            line["also"] = also
+        print(json.dumps(line))
+    sys.stdout.flush()
+    ranks.group.barrier()
+    if ranks.rccl:
+        _lib.call("rmh_comm_destroy")
+    ranks.group.close()
 
 
 if __name__ == "__main__":

@@ -234,11 +234,22 @@ int rmh_run_pt(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, const double *bet
 int rmh_comm_unique_id(uint8_t *id128);
 int rmh_comm_init(const uint8_t *id128, int nranks, int rank);
 int rmh_comm_destroy(void);
-/* all-gather of the ranks' current states: pooled (nranks * N, d), rank-major;
- * every rank must hold the same number of chains N */
+/* ranks of the communicator and this process's rank (0, 0 when there is none) */
+int rmh_comm_info(int *nranks, int *rank);
+/* every rank has drained its stream and reached the call (one 8-byte all-reduce) */
+int rmh_comm_barrier(void);
+/* element-wise reduction over the ranks of a small host buffer, in place on every rank:
+ * op 0 = sum, 1 = max, 2 = min (bench.py: max-over-ranks of the timed region) */
+int rmh_comm_allreduce_host(double *buf, int64_t n, int op);
+/* chains held by every rank (counts[nranks], may be null) and their sum */
+int rmh_comm_pooled_chains(rmh_state_t s, int64_t *total, int64_t *counts);
+/* all-gather of the ranks' current states: pooled (sum of the ranks' N, d), rank-major.
+ * Shards may differ in size (every rank contributes a zero-padded block of the largest
+ * shard to ONE ncclAllGather); size the output with rmh_comm_pooled_chains. */
 int rmh_allgather_samples(rmh_state_t s, double *pooled);
-/* all-reduce (sum) of [count, sum_p theta_p, sum theta_p theta_q]: moments has
- * 1 + d + d*d entries; pooled mean and covariance follow on the host */
+/* duration (HIP events on the library's stream) and bytes contributed per rank of the
+ * last rmh_allgather_samples */
+int rmh_comm_last_ms(double *ms, int64_t *bytes_per_rank);
 int rmh_allreduce_moments(rmh_state_t s, double *moments);
 
 /* ---- test hooks ---------------------------------------------------------- */

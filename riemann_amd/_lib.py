@@ -78,6 +78,11 @@ SIGNATURES = {
     "rmh_comm_unique_id": [_u8],
     "rmh_comm_init": [_u8, _int, _int],
     "rmh_comm_destroy": [],
+    "rmh_comm_info": [C.POINTER(_int), C.POINTER(_int)],
+    "rmh_comm_barrier": [],
+    "rmh_comm_allreduce_host": [_f64, _i64, _int],
+    "rmh_comm_pooled_chains": [_vp, C.POINTER(_i64), _vp],
+    "rmh_comm_last_ms": [C.POINTER(_dbl), C.POINTER(_i64)],
     "rmh_allgather_samples": [_vp, _f64],
     "rmh_allreduce_moments": [_vp, _f64],
     "rmh_debug_rng_stream": [_u64s, _u64s, _i64, _int, _int, _f64, _f64],

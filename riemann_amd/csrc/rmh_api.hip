@@ -918,7 +918,8 @@ int rmh_state_create(rmh_model_t m, int64_t N, uint64_t seed, uint64_t chain0, r
     RMH_NEED_INIT();
     if (!m || N < 1) return fail(RMH_ERR_PARAM, "state: need a model and N >= 1 chains");
     // the kernels address a (rows, ld) array through 32-bit byte offsets (raw buffer instructions)
-    if ((int64_t)16 * m->NT * pad16(N) * 8 >= ((int64_t)1 << 32))
+    // (the HMC momentum parking array is (rows, ld + 128) through the same offsets)
+    if ((int64_t)16 * m->NT * (pad16(N) + 128) * 8 >= ((int64_t)1 << 32))
         return fail(RMH_ERR_PARAM, "state: too many chains for one state at this dimension "
                                    "(rows x chains x 8 bytes must stay below 4 GiB); split the chains "
                                    "over several Samplers");
@@ -1106,6 +1107,8 @@ int rmh_state_free(rmh_state_t s)
     (void)hipFree(s->sc_theta);
     (void)hipFree(s->sc_logpost);
     (void)hipFree(s->sc_accept);
+    (void)hipFree(s->last_theta);
+    (void)hipFree(s->last_logpost);
     (void)hipFree(s->logpost);
     (void)hipFree(s->rng);
     delete s;

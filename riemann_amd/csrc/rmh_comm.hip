@@ -12,6 +12,7 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <string>
+#include <vector>
 
 namespace rmh {
 int comm_fail(int code, const std::string &msg); // rmh_api.hip
@@ -37,6 +38,9 @@ struct Rccl {
 } g_rccl;
 nccl_comm_t g_comm = nullptr;
 int g_nranks = 0, g_rank = 0;
+hipEvent_t g_cev0 = nullptr, g_cev1 = nullptr; // around the last all-gather
+double g_last_ms = 0.0;
+int64_t g_last_bytes = 0;
 
 int load_rccl()
 {
@@ -143,30 +147,116 @@ int rmh_comm_destroy(void)
     return RMH_OK;
 }
 
-int rmh_allgather_samples(rmh_state_t s, double *pooled)
+int rmh_comm_info(int *nranks, int *rank)
 {
-    if (!g_comm) return comm_fail(RMH_ERR_STATE, "rmh_allgather_samples: no communicator (rmh_comm_init)");
+    if (nranks) *nranks = g_comm ? g_nranks : 0;
+    if (rank) *rank = g_comm ? g_rank : 0;
+    return RMH_OK;
+}
+
+// sum / max / min over the ranks of a small host buffer (timing and bookkeeping values)
+int rmh_comm_allreduce_host(double *buf, int64_t n, int op)
+{
+    if (!g_comm) return comm_fail(RMH_ERR_STATE, "rmh_comm_allreduce_host: no communicator (rmh_comm_init)");
+    if (!buf || n < 1 || op < 0 || op > 2) return comm_fail(RMH_ERR_PARAM, "rmh_comm_allreduce_host: bad argument");
+    static const int kOp[3] = {0, 2, 3}; // rccl.h ncclRedOp_t: ncclSum, ncclMax, ncclMin
+    hipStream_t st = comm_stream();
+    double *dev = nullptr;
+    hipError_t e = hipMalloc(&dev, (size_t)n * sizeof(double));
+    if (e != hipSuccess) return comm_fail(RMH_ERR_HIP, hipGetErrorString(e));
+    e = hipMemcpyAsync(dev, buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
+    int r = 0;
+    if (e == hipSuccess) r = g_rccl.AllReduce(dev, dev, (size_t)n, kNcclFloat64, kOp[op], g_comm, st);
+    if (e == hipSuccess && r == 0) e = hipMemcpyAsync(buf, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && r == 0) e = hipStreamSynchronize(st);
+    (void)hipFree(dev);
+    if (r != 0) return comm_fail(RMH_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+    if (e != hipSuccess) return comm_fail(RMH_ERR_HIP, hipGetErrorString(e));
+    return RMH_OK;
+}
+
+// every rank has drained its stream and reached this call
+int rmh_comm_barrier(void)
+{
+    double one = 1.0;
+    return rmh_comm_allreduce_host(&one, 1, 0);
+}
+
+// chains held by every rank (counts[nranks], may be null) and their sum
+int rmh_comm_pooled_chains(rmh_state_t s, int64_t *total, int64_t *counts)
+{
+    if (!g_comm) return comm_fail(RMH_ERR_STATE, "rmh_comm_pooled_chains: no communicator (rmh_comm_init)");
     double *theta;
     int64_t N, ld;
     int d, dp;
     int rc = comm_state_info(s, &theta, &N, &ld, &d, &dp);
     if (rc) return rc;
+    std::vector<double> cnt((size_t)g_nranks, 0.0);
+    cnt[g_rank] = (double)N;
+    if ((rc = rmh_comm_allreduce_host(cnt.data(), g_nranks, 0))) return rc;
+    int64_t tot = 0;
+    for (int k = 0; k < g_nranks; ++k) {
+        if (counts) counts[k] = (int64_t)cnt[k];
+        tot += (int64_t)cnt[k];
+    }
+    if (total) *total = tot;
+    return RMH_OK;
+}
+
+int rmh_comm_last_ms(double *ms, int64_t *bytes_per_rank)
+{
+    if (ms) *ms = g_last_ms;
+    if (bytes_per_rank) *bytes_per_rank = g_last_bytes;
+    return RMH_OK;
+}
+
+// Shards may differ in size (shard_range hands out blocks that differ by one chain): every rank
+// contributes a chain-major (Nmax, d) block, zero padded, to ONE ncclAllGather; the host copy
+// keeps the first N_k chains of rank k.
+int rmh_allgather_samples(rmh_state_t s, double *pooled)
+{
+    if (!g_comm) return comm_fail(RMH_ERR_STATE, "rmh_allgather_samples: no communicator (rmh_comm_init)");
+    if (!pooled) return comm_fail(RMH_ERR_PARAM, "rmh_allgather_samples: null output");
+    double *theta;
+    int64_t N, ld;
+    int d, dp;
+    int rc = comm_state_info(s, &theta, &N, &ld, &d, &dp);
+    if (rc) return rc;
+    std::vector<int64_t> counts((size_t)g_nranks);
+    int64_t total = 0, nmax = 0;
+    if ((rc = rmh_comm_pooled_chains(s, &total, counts.data()))) return rc;
+    for (int64_t n : counts) nmax = n > nmax ? n : nmax;
+    // all ranks must agree on d (one model): the block size is nmax * d doubles
+    double dd[2] = {(double)d, -(double)d};
+    if ((rc = rmh_comm_allreduce_host(dd, 2, 1))) return rc;
+    if (dd[0] != (double)d || dd[1] != -(double)d)
+        return comm_fail(RMH_ERR_PARAM, "rmh_allgather_samples: the ranks' states differ in dimension");
     hipStream_t st = comm_stream();
-    const size_t block = (size_t)dp * ld;
+    const size_t block = (size_t)nmax * d;
     double *all = nullptr, *nd = nullptr;
     hipError_t e = hipMalloc(&all, block * g_nranks * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&nd, (size_t)N * d * sizeof(double));
-    if (e != hipSuccess) {
-        (void)hipFree(all); (void)hipFree(nd);
-        return comm_fail(RMH_ERR_HIP, hipGetErrorString(e));
-    }
-    int r = g_rccl.AllGather(theta, all, block, kNcclFloat64, g_comm, st);
+    if (e == hipSuccess) e = hipMalloc(&nd, block * sizeof(double));
+    if (e == hipSuccess && !g_cev0) e = hipEventCreate(&g_cev0);
+    if (e == hipSuccess && !g_cev1) e = hipEventCreate(&g_cev1);
+    if (e == hipSuccess) e = hipMemsetAsync(nd, 0, block * sizeof(double), st);
+    if (e == hipSuccess) e = launch_transpose_dn_to_nd(theta, nd, N, d, ld, 1, st);
+    int r = 0;
+    if (e == hipSuccess) e = hipEventRecord(g_cev0, st);
+    if (e == hipSuccess) r = g_rccl.AllGather(nd, all, block, kNcclFloat64, g_comm, st);
+    if (e == hipSuccess && r == 0) e = hipEventRecord(g_cev1, st);
+    int64_t off = 0;
     for (int k = 0; k < g_nranks && r == 0 && e == hipSuccess; ++k) {
-        e = launch_transpose_dn_to_nd(all + k * block, nd, N, d, ld, 1, st);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(pooled + (size_t)k * N * d, nd, (size_t)N * d * sizeof(double),
+        if (counts[k] > 0)
+            e = hipMemcpyAsync(pooled + off * d, all + (size_t)k * block, (size_t)counts[k] * d * sizeof(double),
                                hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        off += counts[k];
+    }
+    if (e == hipSuccess && r == 0) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && r == 0) {
+        float f = 0.f;
+        e = hipEventElapsedTime(&f, g_cev0, g_cev1);
+        g_last_ms = f;
+        g_last_bytes = (int64_t)(block * sizeof(double));
     }
     (void)hipFree(all); (void)hipFree(nd);
     if (r != 0) return comm_fail(RMH_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));

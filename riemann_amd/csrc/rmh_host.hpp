@@ -73,6 +73,8 @@ struct rmh_state {
     // scratch history of one AdaptCov segment (every state of <= kAcovChunk iterations)
     double *sc_theta = nullptr, *sc_logpost = nullptr;
     uint8_t *sc_accept = nullptr;
+    // one-entry sink for the last kept state of a run without a history (rmh_run_api.hip)
+    double *last_theta = nullptr, *last_logpost = nullptr;
     uint64_t *rng = nullptr;
     bool valid = false, grad_valid = false;
 };

@@ -265,7 +265,8 @@ static int run_adaptcov(rmh_model *m, rmh_proposal *p, rmh_state *s, const Chain
                 RMH_HIP(hipMemcpyAsync(h->logpost + k * ld, s->sc_logpost + i * ld, (size_t)ld * sizeof(double),
                                        hipMemcpyDeviceToDevice, g_stream));
             }
-            RMH_HIP(hipMemcpyAsync(h->accept + done * ld, s->sc_accept, (size_t)seg * ld, hipMemcpyDeviceToDevice, g_stream));
+            if (h->accept)
+                RMH_HIP(hipMemcpyAsync(h->accept + done * ld, s->sc_accept, (size_t)seg * ld, hipMemcpyDeviceToDevice, g_stream));
         }
         // adapt() after every step: accumulate the states 1..seg of the segment
         RMH_HIP(launch_moments(p->acov_NT, s->sc_theta, 1, seg + 1, (int)rows, ld, s->N, s->d,
@@ -319,6 +320,28 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
     r.h_theta = h ? h->thetas : nullptr;
     r.h_logpost = h ? h->logpost : nullptr;
     r.h_accept = h ? h->accept : nullptr;
+    // The chain's current state after run() is the LAST KEPT entry (sampler.py:49-50, 53-54),
+    // recorded or not.  Without a history and with (T - Nburn) % Nthin != 0 the kernels record
+    // exactly that one state (number `last`) into a one-entry sink of the chain state.
+    const int64_t last = kept > 0 ? nburn + (kept - 1) * nthin : 0;
+    const bool need_last = !h && kept > 0 && last != T;
+    rmh_history sink;
+    if (need_last) {
+        const size_t rows = (size_t)4 * s->ks;
+        if (!s->last_theta) {
+            if ((rc = dev_alloc(&s->last_theta, rows * s->ld)) || (rc = dev_alloc(&s->last_logpost, (size_t)s->ld)))
+                return rc;
+            RMH_HIP(hipMemsetAsync(s->last_theta, 0, rows * s->ld * sizeof(double), g_stream));
+        }
+        sink.s = s;
+        sink.entries = 1;
+        sink.thetas = s->last_theta;
+        sink.logpost = s->last_logpost;
+        r.nburn = last;
+        r.nthin = T + 1;
+        r.h_theta = sink.thetas;
+        r.h_logpost = sink.logpost;
+    }
     if (K > 0) { // parallel tempering: the slots' inverse temperatures
         if ((p->kind != kRW && p->kind != kHMC) || adapt || p->acov || p->nblk > 0 || (p->kind == kHMC && p->d_chM))
             return fail(RMH_ERR_PARAM, "run_pt: built for MetropolisRandomWalk and VanillaHMC / MALA (no mass matrix, "
@@ -359,7 +382,7 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
                                        "adaptation) and for HMC on the Gaussian, mixture (random walk) "
                                        "and logistic models");
         launches = 0;
-        if ((rc = run_adaptcov(m, p, s, c, T, nburn, nthin, h, &launches))) return rc;
+        if ((rc = run_adaptcov(m, p, s, c, T, r.nburn, r.nthin, need_last ? &sink : h, &launches))) return rc;
     } else if (K > 0 && p->kind == kHMC) {
         HmcArgs ha{p->eps, p->nsteps, nullptr, nullptr, nullptr, 1.0};
         e = m->kind == kGauss ? launch_gauss_hmc(m->NT, m->ga, ha, c, r, false, g_stream)
@@ -410,19 +433,18 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
     RMH_HIP(hipEventRecord(g_ev1, g_stream));
     g_timed = true;
     g_last_launches = launches;
+    // every kernel but the HMC ones moves theta and leaves the cached gradient behind
+    if (p->kind != kHMC) s->grad_valid = false;
     // the chain's current state is the LAST KEPT entry (sampler.py:49-50, 53-54)
     if (kept == 0) {
         s->valid = false;
-    } else if (h) {
-        const int64_t last = nburn + (kept - 1) * nthin;
-        if (last != T) {
-            const int64_t rows = 4 * s->ks;
-            RMH_HIP(hipMemcpyAsync(s->theta, h->thetas + (kept - 1) * rows * s->ld,
-                                   (size_t)rows * s->ld * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
-            RMH_HIP(hipMemcpyAsync(s->logpost, h->logpost + (kept - 1) * s->ld,
-                                   (size_t)s->ld * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
-            s->grad_valid = false;
-        }
+    } else if (last != T) {
+        const int64_t rows = 4 * s->ks;
+        const double *src_t = h ? h->thetas + (kept - 1) * rows * s->ld : sink.thetas;
+        const double *src_l = h ? h->logpost + (kept - 1) * s->ld : sink.logpost;
+        RMH_HIP(hipMemcpyAsync(s->theta, src_t, (size_t)rows * s->ld * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
+        RMH_HIP(hipMemcpyAsync(s->logpost, src_l, (size_t)s->ld * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
+        s->grad_valid = false;
     }
     return RMH_OK;
 }

@@ -1,15 +1,28 @@
 """Multi-GPU layout of the chains: one process per GPU, chains sharded by
 GLOBAL chain id, no collective inside the sampling loop; the only exchange is
-an all-gather of samples for pooled diagnostics.
+an all-gather of samples (and an all-reduce of moment sums) for pooled
+diagnostics.
 
 The reference has nothing distributed (README.md:21-23 states the aspiration).
 The random stream is keyed by (seed, global chain id), so the samples of chain
 c are the same whatever the number of ranks -- sharding is exact, not just
 statistically equivalent.
 
-``torch.distributed`` is plumbing here: backend "nccl" is RCCL over xGMI on the
-MI355X node, "gloo" is used by the CPU tests.
+Pure Python + the library's own RCCL communicator (``rmh_comm_*``, RCCL over
+xGMI; csrc/rmh_comm.hip): no PyTorch anywhere in this package.  The only thing
+the ranks exchange outside RCCL is the 128-byte communicator id, which
+:class:`HostGroup` carries over a loopback/TCP socket -- any launcher that sets
+RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (``torch.distributed.run``,
+``mpirun`` wrappers, a shell loop) works, and nothing of the launcher is
+imported here.
 """
+import os
+import pickle
+import socket
+import struct
+import tempfile
+import time
+
 import numpy as np
 
 
@@ -23,72 +36,168 @@ def shard_range(n_chains, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def pool_samples(local, n_chains, group=None, device=None):
-    """All-gather per-rank sample blocks ``(..., n_local, d)`` (chain axis = -2)
-    into the pooled ``(..., n_chains, d)`` array, on every rank.
-
-    Ragged shards are padded to the largest block for the collective (one
-    all_gather of equal-sized tensors) and trimmed afterwards."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    sizes = [shard_range(n_chains, r, world)[1] - shard_range(n_chains, r, world)[0]
-             for r in range(world)]
-    nmax = max(sizes)
-    a = np.ascontiguousarray(local, dtype=np.float64)
-    if a.shape[-2] != sizes[dist.get_rank(group)]:
-        raise ValueError("local block has %d chains, this rank owns %d"
-                         % (a.shape[-2], sizes[dist.get_rank(group)]))
-    pad = np.zeros(a.shape[:-2] + (nmax, a.shape[-1]))
-    pad[..., : a.shape[-2], :] = a
-    t = torch.from_numpy(pad)
-    if device is not None:
-        t = t.to(device)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t, group=group)
-    parts = [o.cpu().numpy()[..., : sizes[r], :] for r, o in enumerate(out)]
-    return np.concatenate(parts, axis=-2)
+# ---------------------------------------------------------------- host group --
+def _send(sock, obj):
+    b = pickle.dumps(obj, protocol=4)
+    sock.sendall(struct.pack("<Q", len(b)) + b)
 
 
-def pooled_moments(local, group=None, device=None):
-    """Pooled mean and covariance over all chains of all ranks from ONE
-    all-reduce of [count, sum, sum of outer products]."""
-    import torch
-    import torch.distributed as dist
-    x = np.asarray(local, dtype=np.float64).reshape(-1, np.shape(local)[-1])
-    d = x.shape[1]
-    acc = np.concatenate([[x.shape[0]], x.sum(axis=0), (x.T @ x).ravel()])
-    t = torch.from_numpy(acc)
-    if device is not None:
-        t = t.to(device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    acc = t.cpu().numpy()
-    n, s, ss = acc[0], acc[1: d + 1], acc[d + 1:].reshape(d, d)
-    mean = s / n
-    return mean, ss / n - np.outer(mean, mean)
+def _recv(sock):
+    def exactly(n):
+        buf = bytearray()
+        while len(buf) < n:
+            chunk = sock.recv(n - len(buf))
+            if not chunk:
+                raise ConnectionError("riemann_amd.distributed: peer closed the rendezvous socket")
+            buf += chunk
+        return bytes(buf)
+    (n,) = struct.unpack("<Q", exactly(8))
+    return pickle.loads(exactly(n))
 
 
-# ---- the same two collectives through the C ABI (RCCL opened by the library) ----
-def cabi_comm_init(rank, world, broadcast_bytes):
-    """Create the library's RCCL communicator.  ``broadcast_bytes(b)`` must return
-    rank 0's 128-byte id on every rank (e.g. a torch.distributed / file broadcast)."""
+class HostGroup(object):
+    """The ranks of one job as a star over TCP sockets (rank 0 = hub): small host-side
+    collectives -- broadcast / all-gather of Python objects, barrier, max -- used to hand out
+    the RCCL id, and as the fallback where RCCL cannot form a communicator (several ranks on
+    one GPU).  Never on the data path: samples move over RCCL (:func:`pool`).
+
+    Rendezvous: rank 0 listens on ``port`` of ``addr``.  With ``port=None`` it takes an
+    ephemeral port and publishes it in a file named after the launcher's process id and
+    MASTER_PORT under the temp directory (all ranks of a node share both), so no second
+    well-known port is needed next to the launcher's own MASTER_PORT store."""
+
+    def __init__(self, rank, world, addr="127.0.0.1", port=None, key=None, timeout=300.0):
+        self.rank, self.world = int(rank), int(world)
+        self._peers, self._hub, self._file = [], None, None
+        if self.world == 1:
+            return
+        if key is None:
+            key = "%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+        path = os.path.join(tempfile.gettempdir(), "rmh_rdzv_%s" % key)
+        deadline = time.time() + timeout
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr if port is not None else "", int(port or 0)))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            if port is None:
+                tmp = "%s.%d" % (path, os.getpid())
+                with open(tmp, "w") as f:
+                    f.write("%d" % srv.getsockname()[1])
+                os.replace(tmp, path)     # atomic: readers see the whole number or nothing
+                self._file = path
+            peers = {}
+            while len(peers) < self.world - 1:
+                c, _ = srv.accept()
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                c.settimeout(timeout)
+                peers[_recv(c)] = c
+            srv.close()
+            self._peers = [peers[r] for r in range(1, self.world)]
+        else:
+            while True:
+                try:
+                    p = port
+                    if p is None:
+                        with open(path) as f:
+                            p = int(f.read())
+                    s = socket.create_connection((addr, int(p)), timeout=5.0)
+                    break
+                except (OSError, ValueError):
+                    if time.time() > deadline:
+                        raise TimeoutError("riemann_amd.distributed: no rendezvous with rank 0 (%s)" % path)
+                    time.sleep(0.05)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.settimeout(timeout)
+            _send(s, self.rank)
+            self._hub = s
+
+    @classmethod
+    def from_env(cls, **kw):
+        """From the launcher's environment (RANK, WORLD_SIZE, MASTER_ADDR; the rendezvous port is
+        RMH_RDZV_PORT if set -- needed across nodes -- else published through the temp directory)."""
+        port = os.environ.get("RMH_RDZV_PORT")
+        return cls(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+                   addr=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                   port=int(port) if port else None, **kw)
+
+    def allgather(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank."""
+        if self.world == 1:
+            return [obj]
+        if self.rank == 0:
+            out = [obj] + [_recv(c) for c in self._peers]
+            for c in self._peers:
+                _send(c, out)
+            return out
+        _send(self._hub, obj)
+        return _recv(self._hub)
+
+    def broadcast(self, obj, src=0):
+        return self.allgather(obj if self.rank == src else None)[src]
+
+    def barrier(self):
+        self.allgather(None)
+
+    def max(self, x):
+        return max(self.allgather(float(x)))
+
+    def close(self):
+        for c in self._peers + ([self._hub] if self._hub else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self._peers, self._hub = [], None
+        if self._file:
+            try:
+                os.unlink(self._file)
+            except OSError:
+                pass
+            self._file = None
+
+
+# ------------------------------------------------- RCCL through the C ABI ----
+def comm_init(group):
+    """Create the library's RCCL communicator over the ranks of ``group``: rank 0 draws the
+    128-byte id (``rmh_comm_unique_id``), the group broadcasts it, every rank joins
+    (``rmh_comm_init``).  The device must be bound (``rmh_init``) first."""
     from . import _lib
     uid = np.zeros(128, dtype=np.uint8)
-    if rank == 0:
+    if group.rank == 0:
         _lib.call("rmh_comm_unique_id", uid)
-    uid = np.frombuffer(broadcast_bytes(uid.tobytes()), dtype=np.uint8).copy()
-    _lib.call("rmh_comm_init", uid, int(world), int(rank))
+    uid = np.frombuffer(group.broadcast(uid.tobytes()), dtype=np.uint8).copy()
+    _lib.call("rmh_comm_init", uid, int(group.world), int(group.rank))
 
 
-def cabi_pool(sampler, world):
-    """(pooled states (world*N, d), pooled mean (d,), pooled covariance (d,d)) of a
-    Sampler's current states over all ranks: one ncclAllGather of the device state
-    blocks and one ncclAllReduce of the moment accumulators."""
+def comm_ranks():
+    """(ranks, rank) of the library's communicator; (0, 0) when there is none."""
+    import ctypes as C
     from . import _lib
-    N, d = sampler.Nchains, sampler.Npars
-    pooled = np.empty((world * N, d))
+    n, r = C.c_int(), C.c_int()
+    _lib.call("rmh_comm_info", C.byref(n), C.byref(r))
+    return n.value, r.value
+
+
+def pool(sampler):
+    """Pooled diagnostics of a Sampler's current states over all ranks, device resident until
+    the final copy: ``(states (sum N_r, d), mean (d,), covariance (d, d), info)`` from ONE
+    ncclAllGather of the ranks' state blocks (ragged shards are padded to the largest) and ONE
+    ncclAllReduce of the moment sums ``[count, sum theta, sum theta theta^T]``."""
+    import ctypes as C
+    from . import _lib
+    d = sampler.Npars
+    total = C.c_int64()
+    _lib.call("rmh_comm_pooled_chains", sampler._state, C.byref(total), None)
+    pooled = np.empty((total.value, d))
     _lib.call("rmh_allgather_samples", sampler._state, pooled)
+    ms, nb = C.c_double(), C.c_int64()
+    _lib.call("rmh_comm_last_ms", C.byref(ms), C.byref(nb))
     mom = np.empty(1 + d + d * d)
     _lib.call("rmh_allreduce_moments", sampler._state, mom)
     mean = mom[1:1 + d] / mom[0]
-    return pooled, mean, mom[1 + d:].reshape(d, d) / mom[0] - np.outer(mean, mean)
+    cov = mom[1 + d:].reshape(d, d) / mom[0] - np.outer(mean, mean)
+    info = {"rccl_ranks": comm_ranks()[0], "allgather_bytes_per_rank": int(nb.value),
+            "allgather_ms": float(ms.value), "pooled_chains": int(total.value)}
+    return pooled, mean, cov, info

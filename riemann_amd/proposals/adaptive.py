@@ -50,7 +50,7 @@ class AdaptCovProposal(DeviceProposal):
 
     The reference adapts ONE chain's proposal from that chain's history.  Here one
     proposal serves all N chains of a Sampler and the accumulators of ``adapt`` are pooled
-    over the chains (over the ranks too once ``distributed.cabi_comm_init`` was called); with
+    over the chains (over the ranks too once ``distributed.comm_init`` was called); with
     one chain this is the reference's algorithm.  Two statements of the reference are read
     as written rather than as executed: ``np.float`` (:81, removed from numpy) is ``float``,
     and ``C = C0 while n < t_adapt`` is applied (:90 assigns it to an unused ``_cov``).

@@ -22,9 +22,11 @@ def _free_port():
 
 def _worker(rank, world, port, n_chains, out_dir):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     from oracle import oracle as orc
-    from riemann_amd.distributed import pool_samples, pooled_moments, shard_range
+    from dist_gloo import pool_samples, pooled_moments
+    from riemann_amd.distributed import shard_range
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
                             world_size=world)
     d, T, seed = 6, 20, 11
@@ -76,3 +78,69 @@ def test_shard_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(10, 2, 2)
+
+
+# ---- the product's own rendezvous (pure Python, no torch): riemann_amd.distributed.HostGroup ----
+def _host_worker(rank, world, key, n_chains, out_dir):
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    from riemann_amd.distributed import HostGroup, shard_range
+    assert "torch" not in sys.modules
+    g = HostGroup(rank, world, key=key, timeout=60.0)
+    uid = g.broadcast(bytes(range(128)) if rank == 0 else None)          # the RCCL id hand-off
+    assert uid == bytes(range(128))
+    assert g.allgather(("r", rank)) == [("r", r) for r in range(world)]
+    assert g.max(10.0 + rank) == 10.0 + world - 1
+    g.barrier()
+    # a sharded run pooled through the host group (small arrays; the data path proper is RCCL)
+    d, T, seed = 5, 12, 7
+    rg = np.random.default_rng(1)
+    th0 = rg.standard_normal((n_chains, d))
+    lo, hi = shard_range(n_chains, rank, world)
+    m, p = orc.Gaussian(np.zeros(d), np.eye(d)), orc.RandomWalk(0.3 * np.eye(d))
+    th = np.ascontiguousarray(th0[lo:hi]).copy()
+    ht, _, _ = orc.run(m, p, th, m.log_posterior(th), orc.rng_seed(seed, hi - lo, chain0=lo), T)
+    pooled = np.concatenate(g.allgather(ht[-1]), axis=0)
+    np.save(os.path.join(out_dir, "host_rank%d.npy" % rank), pooled)
+    g.barrier()
+    g.close()
+
+
+@pytest.mark.parametrize("world,n_chains", [(2, 24), (3, 25)])
+def test_host_group_rendezvous_and_pooling(tmp_path, world, n_chains):
+    import multiprocessing as mp
+    from oracle import oracle as orc
+    ctx = mp.get_context("spawn")
+    key = "test_%d_%d" % (os.getpid(), world)
+    procs = [ctx.Process(target=_host_worker, args=(r, world, key, n_chains, str(tmp_path)))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    d, T, seed = 5, 12, 7
+    th0 = np.random.default_rng(1).standard_normal((n_chains, d))
+    m, p = orc.Gaussian(np.zeros(d), np.eye(d)), orc.RandomWalk(0.3 * np.eye(d))
+    th = th0.copy()
+    ht, _, _ = orc.run(m, p, th, m.log_posterior(th), orc.rng_seed(seed, n_chains), T)
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), "host_rank%d.npy" % r)), ht[-1])
+
+
+def test_product_imports_no_torch():
+    """north_star: pure Python + ctypes host, no PyTorch in the product package."""
+    import re
+    import subprocess
+    pkg = os.path.join(ROOT, "riemann_amd")
+    pat = re.compile(r"^\s*(import|from)\s+torch\b")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                with open(os.path.join(dirpath, f)) as fh:
+                    for i, line in enumerate(fh, 1):
+                        assert not pat.match(line), "%s:%d imports torch" % (os.path.join(dirpath, f), i)
+    code = ("import sys; sys.path.insert(0, %r); import riemann_amd, riemann_amd.distributed, "
+            "riemann_amd.samplers, riemann_amd.proposals, riemann_amd.models, riemann_amd.diagnostics; "
+            "assert 'torch' not in sys.modules" % ROOT)
+    subprocess.check_call([sys.executable, "-c", code])

@@ -475,6 +475,19 @@ def test_rccl_pooling_entry_points_single_rank(ra):
         _lib.call("rmh_allgather_samples", s._state, pooled)
         th, _ = s.current_state()
         np.testing.assert_array_equal(pooled, th)
+        # the rank-count / barrier / host-reduction entries bench.py drives, and the pooled view
+        from riemann_amd import distributed as D
+        assert D.comm_ranks() == (1, 0)
+        _lib.call("rmh_comm_barrier")
+        buf = np.array([3.0, -1.0])
+        _lib.call("rmh_comm_allreduce_host", buf, 2, 1)
+        np.testing.assert_array_equal(buf, [3.0, -1.0])
+        pl, mean, cov, info = D.pool(s)
+        np.testing.assert_array_equal(pl, th)
+        assert info["rccl_ranks"] == 1 and info["pooled_chains"] == N
+        assert info["allgather_bytes_per_rank"] == N * d * 8 and info["allgather_ms"] >= 0.0
+        np.testing.assert_allclose(mean, th.mean(axis=0), rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(cov, np.cov(th.T, bias=True), rtol=1e-9, atol=1e-12)
         mom = np.empty(1 + d + d * d)
         _lib.call("rmh_allreduce_moments", s._state, mom)
         assert mom[0] == N
@@ -693,3 +706,71 @@ def test_gauss_random_walk_around_the_tail_kernel_sizes(ra, orc, d):
     ht, hl, acc = oracle_run(orc, om, orc.RandomWalk(Cp, 0.5), th0, 3, 10)
     np.testing.assert_array_equal(s2._chain_accept, acc)
     np.testing.assert_allclose(s2._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["rw", "mala", "cp", "adaptcov", "bigd"])
+def test_unrecorded_run_ends_in_the_last_kept_state(ra, kind):
+    """Sampler.run leaves the chain at the LAST KEPT entry (sampler.py:49-54) whether or not a
+    history is recorded: run(T, Nburn, Nthin, record=False) with (T - Nburn) % Nthin != 0 must
+    end where the recorded run ends, and continue identically."""
+    from riemann_amd.models import LogisticRegression, MultiGaussianDist
+    from riemann_amd.proposals import MALA, AdaptCovRandomWalk, MetropolisRandomWalk
+    from riemann_amd.workloads import logreg_data
+    g = np.random.default_rng(21)
+
+    def make():
+        if kind == "cp":
+            z = load("g5_changepoint_rw")
+            return cp_model(z), scaled_rw(z), np.repeat(z["theta0"], 5, axis=0)
+        if kind == "mala":
+            X, y = logreg_data(300, 10, seed=4)
+            m = LogisticRegression(X, y, 10.0)
+            return m, MALA(0.2, m), np.zeros((50, 10))
+        d = 130 if kind == "bigd" else 10
+        m = MultiGaussianDist(np.zeros(d), np.eye(d))
+        th0 = np.random.default_rng(22).standard_normal((40, d))
+        if kind == "adaptcov":
+            return m, AdaptCovRandomWalk(0.1 * np.eye(d), t_adapt=10, smooth_adapt=True), th0
+        return m, MetropolisRandomWalk(0.2 * np.eye(d)), th0
+
+    del g
+    out = []
+    for record in (True, False):
+        m, p, th0 = make()
+        s = ra.Sampler(m, p, th0, seed=9)
+        s.run(11, 2, 4, record=record)          # states 2, 6, 10 kept: the chain ends at state 10 of 11
+        th, lp = s.current_state()
+        if record:
+            np.testing.assert_array_equal(th, s._chain_thetas[-1])
+        s.run(5)                                 # and continues from there
+        out.append((th, lp, s._chain_thetas.copy(), s._chain_accept.copy()))
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_cached_gradient_is_dropped_when_another_proposal_moves_the_chain(ra, orc):
+    """HMC caches the gradient at the current state; a random-walk run in between moves the state,
+    so the next HMC run must start from a fresh gradient (hamiltonian.py:27 evaluates it anew)."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk, VanillaHMC
+    d, N = 12, 48
+    g = np.random.default_rng(5)
+    A = g.standard_normal((d, d))
+    Cov = A @ A.T + d * np.eye(d)
+    th0 = g.standard_normal((N, d))
+    m = MultiGaussianDist(np.zeros(d), Cov)
+    hmc, rw = VanillaHMC(0.3, 3, m), MetropolisRandomWalk(0.3 * np.eye(d))
+    s = ra.Sampler(m, hmc, th0, seed=17)
+    om = orc.Gaussian(np.zeros(d), Cov)
+    oh, orw = orc.HMC(0.3, 3, d), orc.RandomWalk(0.3 * np.eye(d))
+    th, st = th0.copy(), orc.rng_seed(17, N)
+    lp = om.log_posterior(th)
+    for prop, oprop, T in ((hmc, oh, 4), (rw, orw, 3), (hmc, oh, 4), (rw, orw, 2), (hmc, oh, 3)):
+        s.proposal = prop
+        s.run(T)
+        ht, hl, acc = orc.run(om, oprop, th, lp, st, T)
+        np.testing.assert_array_equal(s._chain_accept, acc)
+        np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+        np.testing.assert_allclose(s._chain_logpost, hl, rtol=RTOL)

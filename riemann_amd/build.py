@@ -21,7 +21,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++
 
 
 def _newest_source():
-    names = [f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    names = [f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h"))]
     names.append(os.path.join("..", "..", "include", "riemann_hip.h"))
     return max(os.path.getmtime(os.path.join(CSRC, f)) for f in names)
 
@@ -32,8 +32,15 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
 
+    hdr = [f for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    newest_hdr = max([os.path.getmtime(os.path.join(CSRC, f)) for f in hdr] +
+                     [os.path.getmtime(os.path.join(CSRC, "..", "..", "include", "riemann_hip.h"))])
+
     def compile_one(src):
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        if (not force and os.path.exists(obj) and
+                os.path.getmtime(obj) >= max(newest_hdr, os.path.getmtime(os.path.join(CSRC, src)))):
+            return obj
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -323,7 +323,7 @@ int rmh_init(int device)
                         rmh_icdf_table[(r * RMH_ICDF_SUB + j) * RMH_ICDF_NC + k];
         int rc = upload(&g_icdf, pad.data(), pad.size());
         if (rc) return rc;
-        static_assert(RMH_LOGI_NI == 150 && RMH_LOGI_W == 4 && RMH_LOGI_NC == 10, "table shape");
+        static_assert(RMH_LOGI_NI == 600 && RMH_LOGI_W == 16 && RMH_LOGI_NC == 6, "table shape");
         if ((rc = upload(&g_logi, rmh_logistic_table, sizeof(rmh_logistic_table) / sizeof(double)))) return rc;
     }
     g_device = device;
@@ -488,8 +488,8 @@ int rmh_model_logreg_create(const double *X, const double *y, int64_t n, int d, 
             const int F = ((s & 3) << 2) | gg;
             t[s * 64 + gg * 16 + (i ^ F)] = X[row * d + k];
         }
-        ch[CH * XT + k2 * 32 + i] = y[row];
-        ch[CH * XT + k2 * 32 + 16 + i] = 1.0;
+        ch[CH * XT + k2 * 32 + 2 * i] = y[row];       // (y, w) pairs: w = 1 marks a real row
+        ch[CH * XT + k2 * 32 + 2 * i + 1] = 1.0;
     }
     rmh_model *m = new rmh_model;
     m->kind = kLogReg;

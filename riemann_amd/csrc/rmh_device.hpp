@@ -136,85 +136,97 @@ RMH_DEV double log_full(double x)
 
 // ---- link function of the logistic model (not part of the stream spec: the
 // oracle evaluates the same quantities with libm, tolerance-checked) -------------
-// A closed-form version (Cody-Waite exp + v_rcp_f64 with two Newton steps + fdlibm
-// log, ~63 f64 operations per value) was measured first: 0.506 of the FP64 roof
-// against 0.517 for the table below at one wave per SIMD, 0.589 against 0.610 at two.
-// Table (tools/gen_logistic_table.py): |eta| in [0, 37.5) is cut into 150
-// intervals of width 1/4, each with two degree-9 polynomials in t = 2 frac(4|eta|) - 1:
-//   f = log1p(exp(-|eta|)),  s = sigmoid(-|eta|);  worst relative error 2.1e-16.
-// 20 fma + ~10 other operations and ten ds_read_b128 instead of exp + rcp + log:
-// on this chip every VALU cycle is taken from the f64 MFMA pipe.  Beyond 37.5 both
-// functions are < 6e-17 and are taken at the table edge.  tab = table in LDS.
-constexpr int kLogiNI = 150, kLogiNC = 10, kLogiDoubles = kLogiNI * 2 * kLogiNC;
+// Table (tools/gen_logistic_table.py): |eta| in [0, 37.5) is cut into 600 cells of width
+// 1/16, each with two degree-5 polynomials in t = 2 frac(16 |eta|) - 1:
+//   f = log1p(exp(-|eta|)),  s = sigmoid(-|eta|);  worst relative error 5.0e-14.
+// Per (f, s) pair 10 fma, six ds_read_b128 (one 96-byte cell) and ~12 other operations.  On this
+// chip every VALU cycle is taken from the f64 MFMA pipe, so the link function is priced in
+// instructions: round 1 evaluated degree-9 polynomials on cells of width 1/4 (2.1e-16; 18 fma
+// and ten reads per pair, 20 coefficient registers per value in flight -- that register
+// pressure, not the arithmetic, was what spilled the 8-wave kernel); a closed form (Cody-Waite
+// exp + v_rcp_f64 with two Newton steps + fdlibm log, ~63 f64 operations) was slower than
+// either.  Beyond 37.5 both functions are < 6e-17 and are taken at the table edge.
+// tab = table in LDS (57.6 KB).
+constexpr int kLogiNI = 600, kLogiNC = 6, kLogiCell = 2 * kLogiNC, kLogiDoubles = kLogiNI * kLogiCell;
 
-// split in two so that a kernel can put independent MFMAs between the gather and
-// its first use (one wave per SIMD has nothing else to cover the LDS latency with)
-struct LogiGather {
-    typedef double d2_t __attribute__((ext_vector_type(2)));
-    d2_t c[10];
-    double t;
-};
-
-RMH_DEV void logistic_gather(double eta, const double *tab, LogiGather &q)
+// N values in lockstep: all cells' reads first, then the Horner chains alternating (as
+// normals_lockstep).  VALUE: lse = log(1 + exp(eta)) and sg = sigmoid(eta); else sg only
+// (gradient-only evaluations inside an HMC trajectory: half the cell).
+template <int N, bool VALUE>
+RMH_DEV void logistic_lockstep(const double (&eta)[N], const double *tab, double (&lse)[N], double (&sg)[N])
 {
-    double a = __builtin_fabs(eta);
-    a = (a < 37.4999999) ? a : 37.4999999;
-    const double u = a * 4.0;
-    const int idx = (int)u;
-    q.t = fma_(2.0, u - __builtin_floor(u), -1.0);
-    const LogiGather::d2_t *c = static_cast<const LogiGather::d2_t *>(
-        __builtin_assume_aligned(tab + idx * (2 * kLogiNC), 16));
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    double t[N];
+    const d2_t *c[N];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) q.c[k] = c[k];
-}
-
-// sigmoid only (gradient-only evaluations inside an HMC trajectory): half the table
-RMH_DEV double logistic_sigmoid(double eta, const double *tab)
-{
-    typedef double d2_t __attribute__((ext_vector_type(2)));
-    double a = __builtin_fabs(eta);
-    a = (a < 37.4999999) ? a : 37.4999999;
-    const double u = a * 4.0;
-    const int idx = (int)u;
-    const double t = fma_(2.0, u - __builtin_floor(u), -1.0);
-    const d2_t *c = static_cast<const d2_t *>(
-        __builtin_assume_aligned(tab + idx * (2 * kLogiNC) + kLogiNC, 16));
-    const d2_t s01 = c[0], s23 = c[1], s45 = c[2], s67 = c[3], s89 = c[4];
-    double sv = s89.y;
-    sv = fma_(sv, t, s89.x);
-    sv = fma_(sv, t, s67.y);
-    sv = fma_(sv, t, s67.x);
-    sv = fma_(sv, t, s45.y);
-    sv = fma_(sv, t, s45.x);
-    sv = fma_(sv, t, s23.y);
-    sv = fma_(sv, t, s23.x);
-    sv = fma_(sv, t, s01.y);
-    sv = fma_(sv, t, s01.x);
-    return (eta >= 0.0) ? 1.0 - sv : sv;
-}
-
-RMH_DEV void logistic_finish(double eta, const LogiGather &q, double &lse, double &sg)
-{
-    const double t = q.t;
-    double f = q.c[4].y, sv = q.c[9].y;
-    f = fma_(f, t, q.c[4].x);  sv = fma_(sv, t, q.c[9].x);
-    f = fma_(f, t, q.c[3].y);  sv = fma_(sv, t, q.c[8].y);
-    f = fma_(f, t, q.c[3].x);  sv = fma_(sv, t, q.c[8].x);
-    f = fma_(f, t, q.c[2].y);  sv = fma_(sv, t, q.c[7].y);
-    f = fma_(f, t, q.c[2].x);  sv = fma_(sv, t, q.c[7].x);
-    f = fma_(f, t, q.c[1].y);  sv = fma_(sv, t, q.c[6].y);
-    f = fma_(f, t, q.c[1].x);  sv = fma_(sv, t, q.c[6].x);
-    f = fma_(f, t, q.c[0].y);  sv = fma_(sv, t, q.c[5].y);
-    f = fma_(f, t, q.c[0].x);  sv = fma_(sv, t, q.c[5].x);
-    lse = ((eta > 0.0) ? eta : 0.0) + f;
-    sg = (eta >= 0.0) ? 1.0 - sv : sv;
+    for (int i = 0; i < N; ++i) {
+        double u = __builtin_fabs(eta[i]) * 16.0;
+        u = (u < 599.9999999) ? u : 599.9999999;       // NaN lands on the edge cell too
+        const int idx = (int)u;
+        t[i] = fma_(2.0, __builtin_amdgcn_fract(u), -1.0);
+        // 96-byte cells: v_mul_u32_u24 (full rate; a plain 32-bit multiply is a quarter-rate op)
+        c[i] = reinterpret_cast<const d2_t *>(__builtin_assume_aligned(
+            reinterpret_cast<const char *>(tab) + __umul24((unsigned)idx, (unsigned)(kLogiCell * 8)), 16));
+    }
+    d2_t cf[N][3], cs[N][3];
+#pragma unroll
+    for (int k = 2; k >= 0; --k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            cs[i][k] = c[i][3 + k];
+            if (VALUE) cf[i][k] = c[i][k];
+        }
+    double f[N], sv[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        sv[i] = cs[i][2].y;
+        if (VALUE) f[i] = cf[i][2].y;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        sv[i] = fma_(sv[i], t[i], cs[i][2].x);
+        if (VALUE) f[i] = fma_(f[i], t[i], cf[i][2].x);
+    }
+#pragma unroll
+    for (int k = 1; k >= 0; --k) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            sv[i] = fma_(sv[i], t[i], cs[i][k].y);
+            if (VALUE) f[i] = fma_(f[i], t[i], cf[i][k].y);
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            sv[i] = fma_(sv[i], t[i], cs[i][k].x);
+            if (VALUE) f[i] = fma_(f[i], t[i], cf[i][k].x);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        // max(eta, 0) + f with max(eta, 0) = (eta + |eta|) / 2, exact (a compare-free form: the
+        // select compiles to two v_max_f64, the first only to quiet a signalling NaN)
+        if (VALUE) lse[i] = fma_(0.5, eta[i] + __builtin_fabs(eta[i]), f[i]);
+        sg[i] = (eta[i] >= 0.0) ? 1.0 - sv[i] : sv[i];
+    }
 }
 
 RMH_DEV void logistic_terms(double eta, const double *tab, double &lse, double &sg)
 {
-    LogiGather q;
-    logistic_gather(eta, tab, q);
-    logistic_finish(eta, q, lse, sg);
+    const double e[1] = {eta};
+    double l[1], s[1];
+    logistic_lockstep<1, true>(e, tab, l, s);
+    lse = l[0];
+    sg = s[0];
+}
+
+// t <- fma(row-broadcast of lane N of c, x, t): the DPP row broadcast of v_fmac_f64
+// (row_newbcast: lane N of the own 16-lane row).  The DPP source must not have been written by
+// the VALU in the two preceding wait states; the compiler does not see inside the asm,
+// tools/check_dpp_hazards.py checks the build (riemann_amd/build.py runs it on every build).
+template <int N>
+RMH_DEV void fmac_bcast(double &t, double c, double x)
+{
+    static_assert(N >= 0 && N < 16, "lane of the 16-lane row");
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(c), "v"(x), "n"(N));
 }
 
 // ---- two standard normals per 64-bit word: table-driven inverse CDF (rmh-rng v3)

@@ -3,6 +3,8 @@
 #include "rmh_run.hpp"
 #include "rmh_launch.hpp"
 
+#include <cstdlib>
+
 namespace rmh {
 
 // ------------------------------------------------------- logistic regression
@@ -59,6 +61,13 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
         // s_waitcnt / barrier gaps of the stage loop: 0.52 -> 0.61 of the FP64 roof,
         // although the 256-register cap costs ~300 spilled registers outside the loop.
         constexpr int NW = (kNT >= 5) ? 8 : 4;
+        if constexpr (kNT == 7) { // d = 97..100: columns 96..99 of the gradient on the VALU (rmh_models.hpp)
+            if (m.ks == 25 && r.pt_K == 0 && !p.chM && !getenv("RMH_NO_TAIL")) {
+                using MT = LogRegModel<7, true>;
+                if (adapt) return launch(k_run_hmc<MT, NW, true, false>, c.nblocks, NW, lds, st, m, p, c, r);
+                return launch(k_run_hmc<MT, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);
+            }
+        }
         if (r.pt_K > 0) // parallel tempering: plain HMC / MALA within the rungs
             return launch(k_run_hmc<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
         if (p.chM) { // mass-matrix variant: one wave per SIMD (register budget)

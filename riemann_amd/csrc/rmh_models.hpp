@@ -193,8 +193,15 @@ struct MixModel {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
-template <int NT>
+// GT ("gradient tail", d = 97..100 only): the seventh 16-column tile of the gradient product holds
+// 4 real columns; v_mfma_f64 and the VALU share the FP64 units on this chip, so those 4 columns
+// are cheaper as 16 DPP fmas per row tile than as 4 MFMAs (as the four tail rows of
+// k_run_rw_tail, rmh_run.hpp): lane (g, cl = 4r + c) reads X[row 4r+g][column 96+c] with ONE
+// ds_read_b64, the fmas take it by row broadcast, and every lane accumulates its own data rows'
+// share of the four columns; the chain's four lanes meet once per evaluation (sum4_scatter).
+template <int NT, bool GT = false>
 struct LogRegModel {
+    static_assert(!GT || NT == 7, "the gradient tail is the d = 97..100 case");
     using Args = LogRegArgs;
     using T = Tile<NT>;
     static constexpr int S = T::S;
@@ -202,6 +209,8 @@ struct LogRegModel {
     static constexpr int XT = 256 * NT;            // doubles of one row tile's X tiles
     static constexpr int CHD = kChunkDoubles(NT);  // doubles per stage
     static constexpr int NP = CHD / 128;           // 1-KiB DMA pieces per stage
+    static constexpr int NG = GT ? NT - 1 : NT;    // gradient row tiles on the matrix core
+    static constexpr int KS = GT ? 25 : 0;         // k-steps of eta when known at compile time
 
     static constexpr __host__ __device__ size_t lds_doubles(bool) { return (size_t)2 * CHD + kLogiDoubles; }
     // LDS: [stage 0][stage 1][link-function table]
@@ -227,53 +236,102 @@ struct LogRegModel {
         double4_t eta = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < S; ++s) // k-steps beyond ceil(d/4) multiply zero columns: skipped
-            if (s < S - 4 || s < ks) eta = mfma(img[s * 64 + eoff[s & 3]], th[s], eta);
+            if (KS > 0 ? s < KS : (s < S - 4 || s < ks)) eta = mfma(img[s * 64 + eoff[s & 3]], th[s], eta);
         return eta;
     }
 
+    struct GradTail {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        // columns 96..99 of X^T res for the lane's four data rows; xv = this lane's entry
+        RMH_DEV void add(double xv, const double (&res)[4])
+        {
+            fmac_bcast<0>(t0, xv, res[0]);  fmac_bcast<1>(t1, xv, res[0]);
+            fmac_bcast<2>(t2, xv, res[0]);  fmac_bcast<3>(t3, xv, res[0]);
+            fmac_bcast<4>(t0, xv, res[1]);  fmac_bcast<5>(t1, xv, res[1]);
+            fmac_bcast<6>(t2, xv, res[1]);  fmac_bcast<7>(t3, xv, res[1]);
+            fmac_bcast<8>(t0, xv, res[2]);  fmac_bcast<9>(t1, xv, res[2]);
+            fmac_bcast<10>(t2, xv, res[2]); fmac_bcast<11>(t3, xv, res[2]);
+            fmac_bcast<12>(t0, xv, res[3]); fmac_bcast<13>(t1, xv, res[3]);
+            fmac_bcast<14>(t2, xv, res[3]); fmac_bcast<15>(t3, xv, res[3]);
+        }
+    };
+
+    // G += X^T res for the NG column tiles on the matrix core: 4 k-steps (the lane's data rows
+    // 4r + g) x NG MFMAs.  The A operands of k-step r + 1 are read while the MFMAs of k-step r
+    // issue (a0 = those of k-step 0, read by the caller before the link function): left to
+    // itself the compiler reads every pair of operands right before its two MFMAs and waits
+    // for the LDS twelve times per row tile.  sched_barrier pins the order.
     static RMH_DEV void grad_tile(const double *img, const int (&goff)[4], const double (&res)[4],
-                                  double4_t (&G)[NT])
+                                  const double (&a0)[NG], double4_t (&G)[NG])
     {
+        double a[2][NG];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) a[0][i] = a0[i];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            if (r < 3) {
 #pragma unroll
-            for (int i = 0; i < NT; ++i) G[i] = mfma(img[i * 256 + goff[r]], res[r], G[i]);
+                for (int i = 0; i < NG; ++i) a[(r + 1) & 1][i] = img[i * 256 + goff[r + 1]];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < NG; ++i) G[i] = mfma(a[r & 1][i], res[r], G[i]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
-    static RMH_DEV double comp(const double4_t &v, int r)
-    {
-        return (r == 0) ? v.x : (r == 1) ? v.y : (r == 2) ? v.z : v.w;
-    }
-
     // One stage = CH row tiles, one after the other: eta (4*NT MFMAs), link function
-    // of the lane's 4 values, gradient (4*NT MFMAs).  Measured alternatives that were
-    // slower on MI355X: all eta / all link / all gradient phases (0.48 vs 0.51 of the
+    // of the lane's 4 values (in lockstep), gradient (4*NT MFMAs).  Measured alternatives that
+    // were slower on MI355X: all eta / all link / all gradient phases (0.48 vs 0.51 of the
     // roof; 8 values in flight spill into AGPR traffic) and a hand pipeline that
     // parks the table gathers across the next MFMA block (0.48; 160 more live VGPRs).
+    // Per row tile the y / weight block holds 16 (y, w) pairs: w = 1 for real rows, 0 for padding.
+    // Everything a row tile reads that does not depend on its own arithmetic -- the (y, w) pairs,
+    // the tail entry, the first gradient operands -- is read BEFORE the eta chain.
     template <bool GRAD, bool VALUE>
     static RMH_DEV void stage_compute(const double *cur, const double *ltab, const int (&eoff)[4],
-                                      const int (&goff)[4], int g, int ks, const double (&th)[S],
-                                      double &ll, double4_t (&G)[NT])
+                                      const int (&goff)[4], int toff, int g, int ks, const double (&th)[S],
+                                      double &ll, double4_t (&G)[NG], GradTail &gt)
     {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-            const double *img = cur + k * XT, *yw = cur + CH * XT + k * 32;
+            const double *img = cur + k * XT;
+            const d2_t *yw = static_cast<const d2_t *>(__builtin_assume_aligned(cur + CH * XT + k * 32, 16));
+            d2_t p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = yw[4 * r + g];           // (y, w) of data row 4r + g
+            double xv = 0.0, a0[NG];
+            if (GRAD) {
+                if (GT) xv = img[24 * 64 + toff];
+#pragma unroll
+                for (int i = 0; i < NG; ++i) a0[i] = img[i * 256 + goff[0]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             const double4_t eta = eta_tile(img, eoff, ks, th);
-            double res[4];
+            __builtin_amdgcn_sched_barrier(0);
+            const double e[4] = {eta.x, eta.y, eta.z, eta.w};
+            double lse[4], sg[4], res[4];
+            if (VALUE) { // twelve coefficient pairs per value: two values at a time (registers)
+                const double e01[2] = {e[0], e[1]}, e23[2] = {e[2], e[3]};
+                double l01[2], s01[2], l23[2], s23[2];
+                logistic_lockstep<2, true>(e01, ltab, l01, s01);
+                logistic_lockstep<2, true>(e23, ltab, l23, s23);
+                lse[0] = l01[0]; lse[1] = l01[1]; lse[2] = l23[0]; lse[3] = l23[1];
+                sg[0] = s01[0];  sg[1] = s01[1];  sg[2] = s23[0];  sg[3] = s23[1];
+            } else {
+                logistic_lockstep<4, false>(e, ltab, lse, sg);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double e = comp(eta, r), yv = yw[4 * r + g], wv = yw[16 + 4 * r + g];
-                double lse, sg;
-                if (VALUE) {
-                    logistic_terms(e, ltab, lse, sg);
-                    ll += wv * (yv * e - lse);
-                } else { // gradient-only evaluation: the log-likelihood value is not needed
-                    sg = logistic_sigmoid(e, ltab);
-                }
-                res[r] = wv * (yv - sg);
+                if (VALUE) ll = fma_(p[r].y, fma_(p[r].x, e[r], -lse[r]), ll);
+                res[r] = p[r].y * (p[r].x - sg[r]);
             }
-            if (GRAD) grad_tile(img, goff, res, G);
+            if (GRAD) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (GT) gt.add(xv, res);
+                grad_tile(img, goff, res, a0, G);
+            }
         }
     }
 
@@ -291,9 +349,13 @@ struct LogRegModel {
             eoff[k] = g * 16 + (cl ^ ((k << 2) | g));
             goff[k] = (cl >> 2) * 64 + (cl & 3) * 16 + ((4 * k + g) ^ cl);
         }
-        double4_t G[NT];
+        // gradient tail: lane (g, cl = 4r + c) holds X[row 4r + g][column 96 + c] = tile 24,
+        // slot c*16 + (row ^ F) with F = c (image layout above)
+        const int toff = (cl & 3) * 16 + ((4 * (cl >> 2) + g) ^ (cl & 3));
+        double4_t G[NG];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) G[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < NG; ++i) G[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+        GradTail gt;
         double ll = 0.0;
         __syncthreads(); // previous users of the staging buffers are done
         stage(m, 0, lds);
@@ -301,7 +363,7 @@ struct LogRegModel {
         for (int64_t c = 0; c < m.nchunks; ++c) {
             const double *cur = lds + (c & 1) * CHD;
             if (c + 1 < m.nchunks) stage(m, c + 1, lds + ((c + 1) & 1) * CHD);
-            stage_compute<GRAD, VALUE>(cur, lds + 2 * CHD, eoff, goff, g, m.ks, th, ll, G);
+            stage_compute<GRAD, VALUE>(cur, lds + 2 * CHD, eoff, goff, toff, g, m.ks, th, ll, G, gt);
             __syncthreads();
         }
         ll = sum4(ll);
@@ -314,7 +376,17 @@ struct LogRegModel {
         parts[0] = logP;
         parts[1] = ll;
         if (GRAD) {
-            T::unpack(G, grad);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                grad[4 * i + 0] = G[i].x;
+                grad[4 * i + 1] = G[i].y;
+                grad[4 * i + 2] = G[i].z;
+                grad[4 * i + 3] = G[i].w;
+            }
+            if (GT) { // rows 96..99: lane group g keeps row 96 + g (tile 6, register 0)
+                grad[24] = sum4_scatter(gt.t0, gt.t1, gt.t2, gt.t3);
+                grad[25] = grad[26] = grad[27] = 0.0;
+            }
 #pragma unroll
             for (int s = 0; s < S; ++s) grad[s] = grad[s] - th[s] * m.inv_tau2;
         }

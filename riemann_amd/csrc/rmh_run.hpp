@@ -302,14 +302,6 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
 // compiler does not see inside the asm, tools/check_dpp_hazards.py (a CPU test) checks the build.
 constexpr int kTailS = 25, kTailGroups = 7, kTailDoubles = kTailGroups * 64;
 
-// t <- fma(row-broadcast of lane N of c, x, t)
-template <int N>
-RMH_DEV void fmac_bcast(double &t, double c, double x)
-{
-    static_assert(N >= 0 && N < 16, "lane of the 16-lane row");
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(c), "v"(x), "n"(N));
-}
-
 struct TailAcc {
     double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
     double c[kTailGroups];

@@ -49,6 +49,19 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(compile_one, SOURCES))
+    # inline-asm DPP instructions are outside the compiler's hazard recogniser: scan the
+    # disassembly of the objects that are about to be linked and refuse a hazardous build
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "check_dpp_hazards", os.path.join(HERE, "..", "tools", "check_dpp_hazards.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    total, bad = chk.check_objects(objs)
+    if bad:
+        raise RuntimeError("DPP data hazards in the built kernels (tools/check_dpp_hazards.py):\n  " +
+                           "\n  ".join(bad[:20]))
+    if verbose:
+        print("DPP hazard scan: %d DPP instructions, none hazardous" % total)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"])
     return SO
 

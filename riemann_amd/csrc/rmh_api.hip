@@ -195,7 +195,8 @@ int ensure_grad(rmh_state *s)
         RMH_HIP(hipMemsetAsync(s->grad, 0, (size_t)s->dp * s->ld * sizeof(double), g_stream));
     }
     if (!s->mom) {
-        int rc = dev_alloc(&s->mom, (size_t)s->dp * (s->ld + 128));
+        // (dp + 4, ld + 128): the last four rows park per-lane scalars (k_run_hmc)
+        int rc = dev_alloc(&s->mom, (size_t)(s->dp + 4) * (s->ld + 128));
         if (rc) return rc;
     }
     ChainArgs c = chain_args(s);
@@ -919,7 +920,7 @@ int rmh_state_create(rmh_model_t m, int64_t N, uint64_t seed, uint64_t chain0, r
     if (!m || N < 1) return fail(RMH_ERR_PARAM, "state: need a model and N >= 1 chains");
     // the kernels address a (rows, ld) array through 32-bit byte offsets (raw buffer instructions)
     // (the HMC momentum parking array is (rows, ld + 128) through the same offsets)
-    if ((int64_t)16 * m->NT * (pad16(N) + 128) * 8 >= ((int64_t)1 << 32))
+    if ((int64_t)(16 * m->NT + 4) * (pad16(N) + 128) * 8 >= ((int64_t)1 << 32))
         return fail(RMH_ERR_PARAM, "state: too many chains for one state at this dimension "
                                    "(rows x chains x 8 bytes must stay below 4 GiB); split the chains "
                                    "over several Samplers");

@@ -87,13 +87,30 @@ RMH_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c
 // log core: x positive, normal, finite; the result is log(x) + koff*ln2 with the
 // exponent offset applied BEFORE the final expression (as the oracle does for
 // subnormal inputs: k = -54 after scaling by 2^54).
+// OPQ: the polynomial's constants are made opaque at their use.  As plain constants the compiler
+// hoists their VGPR copies (v_fmac wants its addend in a register) to kernel entry; in the HMC
+// kernels, whose stage loop runs at the register cap, that put five of them in scratch.
+// (the constant enters as two 32-bit literals of v_mov_b32 in a volatile asm: nothing about it is
+// loop-invariant code the compiler could hoist -- an opaque copy of a constant still is)
+#define RMH_LGC(x) lgc<OPQ, (uint32_t)(__builtin_bit_cast(uint64_t, (double)(x)) >> 32), \
+                       (uint32_t)__builtin_bit_cast(uint64_t, (double)(x))>(x)
+template <bool OPQ, uint32_t HI, uint32_t LO>
+RMH_DEV double lgc(double x)
+{
+    if (!OPQ) return x;
+    uint32_t lo, hi;
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(lo), "=v"(hi) : "n"(LO), "n"(HI));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+template <bool OPQ = false>
 RMH_DEV double log_core(double x, int koff)
 {
-    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
-                     Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
-                     Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
-                     Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                     Lg7 = 1.479819860511658591e-01;
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = RMH_LGC(6.666666666666735130e-01), Lg2 = RMH_LGC(3.999999999940941908e-01),
+                 Lg3 = RMH_LGC(2.857142874366239149e-01), Lg4 = RMH_LGC(2.222219843214978396e-01),
+                 Lg5 = RMH_LGC(1.818357216161805012e-01), Lg6 = RMH_LGC(1.531383769920937332e-01),
+                 Lg7 = RMH_LGC(1.479819860511658591e-01);
     const uint64_t ix = (uint64_t)__double_as_longlong(x);
     int k = (int)(ix >> 52) - 1023 + koff;
     const uint64_t mant = ix & 0x000FFFFFFFFFFFFFULL;
@@ -114,7 +131,8 @@ RMH_DEV double log_core(double x, int koff)
 }
 
 // log of a positive, normal, finite double (all the stream needs): no specials.
-RMH_DEV double log_pos(double x) { return log_core(x, 0); }
+template <bool OPQ = false>
+RMH_DEV double log_pos(double x) { return log_core<OPQ>(x, 0); }
 
 // log with IEEE/numpy specials: nan->nan, <0 -> nan, 0 -> -inf, inf -> inf,
 // subnormals rescaled by 2^54.
@@ -379,11 +397,12 @@ RMH_DEV double combine_post(double logP, double logL)
 
 // Sampler.sample, riemann/samplers/sampler.py:83-84, with PYTHON min(0, D):
 // D if D < 0 else 0, so a NaN ratio accepts.
+template <bool OPQ = false>
 RMH_DEV bool mh_accept(double lp_prop, double lp_old, double logq, double u)
 {
     const double delta = lp_prop - lp_old - logq;
     const double mh = (delta < 0.0) ? delta : 0.0;
-    const double lu = (u > 0.0) ? log_pos(u) : -__builtin_huge_val();
+    const double lu = (u > 0.0) ? log_pos<OPQ>(u) : -__builtin_huge_val();
     return lu < mh;
 }
 

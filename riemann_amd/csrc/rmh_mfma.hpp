@@ -52,6 +52,39 @@ RMH_DEV void buf_store(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, d
     __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
 
+// xoshiro state through raw buffer instructions: one descriptor and ONE 32-bit lane offset for the
+// four words (flat addressing keeps four 64-bit addresses alive from the load at kernel entry to
+// the store at its end -- in the HMC kernels those were spilled to scratch)
+RMH_DEV Xo xo_load_buf(const uint64_t *rng, int64_t nslots, int64_t slot)
+{
+    const __amdgpu_buffer_rsrc_t r = rsrc(rng, 4 * nslots);
+    const uint32_t voff = (uint32_t)slot * 8u, row = (uint32_t)nslots * 8u;
+    Xo x;
+    x.s0 = (uint64_t)__double_as_longlong(buf_load(r, voff, 0u));
+    x.s1 = (uint64_t)__double_as_longlong(buf_load(r, voff, row));
+    x.s2 = (uint64_t)__double_as_longlong(buf_load(r, voff, 2u * row));
+    x.s3 = (uint64_t)__double_as_longlong(buf_load(r, voff, 3u * row));
+    return x;
+}
+
+RMH_DEV void xo_store_buf(uint64_t *rng, int64_t nslots, int64_t slot, const Xo &x)
+{
+    const __amdgpu_buffer_rsrc_t r = rsrc(rng, 4 * nslots);
+    const uint32_t voff = (uint32_t)slot * 8u, row = (uint32_t)nslots * 8u;
+    buf_store(r, voff, 0u, __longlong_as_double((long long)x.s0));
+    buf_store(r, voff, row, __longlong_as_double((long long)x.s1));
+    buf_store(r, voff, 2u * row, __longlong_as_double((long long)x.s2));
+    buf_store(r, voff, 3u * row, __longlong_as_double((long long)x.s3));
+}
+
+// one byte per lane through a raw buffer store (the accept flags)
+RMH_DEV void buf_store_u8(uint8_t *base, int64_t bytes, uint32_t voff, uint8_t x)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+        base, 0, bytes > 0xFFFFFFFFLL ? (int)0xFFFFFFFF : (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b8(x, r, voff, 0, 0);
+}
+
 template <int NT>
 struct Tile {
     static constexpr int S = 4 * NT;

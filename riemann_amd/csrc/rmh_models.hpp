@@ -22,6 +22,7 @@ struct GaussModel {
     using Args = GaussArgs;
     using T = Tile<NT>;
     static constexpr int S = T::S;
+    static constexpr bool kDim100 = false;          // d known to be 97..100 at compile time
     static constexpr int kImg = tri_tiles(NT) * 64; // doubles per triangular image
 
     static constexpr __host__ __device__ size_t lds_doubles(bool grad) { return (size_t)kImg * (grad ? 2 : 1) + 4 * S; }
@@ -111,6 +112,7 @@ struct MixModel {
     using Args = MixArgs;
     using T = Tile<NT>;
     static constexpr int S = T::S;
+    static constexpr bool kDim100 = false;
     static constexpr int kImg = tri_tiles(NT) * 64;
 
     static constexpr __host__ __device__ size_t lds_doubles(bool) { return 0; }
@@ -209,6 +211,7 @@ struct LogRegModel {
     static constexpr int XT = 256 * NT;            // doubles of one row tile's X tiles
     static constexpr int CHD = kChunkDoubles(NT);  // doubles per stage
     static constexpr int NP = CHD / 128;           // 1-KiB DMA pieces per stage
+    static constexpr bool kDim100 = GT;
     static constexpr int NG = GT ? NT - 1 : NT;    // gradient row tiles on the matrix core
     static constexpr int KS = GT ? 25 : 0;         // k-steps of eta when known at compile time
 
@@ -355,8 +358,13 @@ struct LogRegModel {
         double4_t G[NG];
 #pragma unroll
         for (int i = 0; i < NG; ++i) G[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+        // (an opaque zero: as a plain constant the compiler materialises these five initial values
+        // once at kernel entry and keeps them in scratch until every evaluation)
+        double zero = 0.0;
+        asm volatile("" : "+v"(zero));
         GradTail gt;
-        double ll = 0.0;
+        gt.t0 = gt.t1 = gt.t2 = gt.t3 = zero;
+        double ll = zero;
         __syncthreads(); // previous users of the staging buffers are done
         stage(m, 0, lds);
         __syncthreads();

@@ -31,7 +31,8 @@ struct Keep {
         if (!run.h_theta || !active) return;
         double *dst = run.h_theta + k * (int64_t)(4 * ch.ks) * ch.ld;
         Tile<NT>::template store_rows<KS>(dst, ch.ld, c, g, KS > 0 ? KS : ch.ks, th);
-        if (g == 0) run.h_logpost[k * ch.ld + c] = lp;
+        // (raw buffer store: a flat one keeps a 64-bit address per lane alive across the iteration)
+        if (g == 0) buf_store(rsrc(run.h_logpost + k * ch.ld, ch.ld), (uint32_t)c * 8u, 0u, lp);
     }
 };
 
@@ -536,8 +537,18 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
     // momentum parking column: ch.mom is (dp, ld + 128); the idle waves of the
     // last workgroup (which shadow its last block) get columns of their own
     const int64_t cm = active ? c : ch.ld + wave * 16 + cl;
+    // Between uses the chain's scalars live in memory too (not in registers that would be
+    // spilled across the evaluations): the log posterior in ch.logpost (read before the accept
+    // test, written on accept; PT keeps the tempered value in a register), the kinetic energy
+    // of the draw in four spare rows of the momentum parking array.
+    // (descriptors are rebuilt from the kernel arguments at every use: held, they cost scalar
+    // registers across the evaluations, and the kernel runs at the scalar register cap too)
+    constexpr bool LPMEM = !PT;
+    auto rs_lp = [&]() { return rsrc(ch.logpost, ch.ld); };
+    auto rs_k0 = [&]() { return rsrc(ch.mom + (int64_t)(4 * S) * (ch.ld + 128), 4 * (ch.ld + 128)); };
+    const uint32_t vo_lp = (uint32_t)c * 8u, vo_k0 = (uint32_t)(g * (ch.ld + 128) + cm) * 8u;
     double lp = ch.logpost[c];
-    Xo rng = xo_load(ch.rng, ch.nslots, slot);
+    Xo rng = xo_load_buf(ch.rng, ch.nslots, slot);
     double eps = pr.eps, heps = 0.5 * pr.eps;
     Keep keep(run);
     AdaptScale ad{0.0, 0.0, 1.0};
@@ -580,8 +591,14 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
                 prev = in;
             }
         }
-        if (t < run.T) T::normals(rng, ch.M, ch.d, g, tab, p);
+        if (t < run.T) {
+            // d = 97..100 (the model's compile-time case): 13 words per sub-stream, no wave-uniform
+            // word and k-step predicates (rmh_mfma.hpp)
+            if constexpr (M::kDim100) T::template normals_fixed<13, 100>(rng, ch.d, g, tab, p);
+            else T::normals(rng, ch.M, ch.d, g, tab, p);
+        }
         T::load_state(ch.theta, ch.ld, c, g, q);
+        if (LPMEM) lp = buf_load(rs_lp(), vo_lp, 0u);
         keep.record<NT>(run, ch, t, c, g, active, q, lp);
         if (t == run.T) break;
         if (ADAPT) { // AdaptScaleHMC.propose: eps = scale * eps0 (hamiltonian.py:101-102)
@@ -591,6 +608,10 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
         double k0 = 0.0;
 #pragma unroll
         for (int s = 0; s < S; ++s) k0 += p[s] * p[s];   // K of the N(0,I) draw (= |chM^-1 p0|^2)
+        // k0 is used after the trajectory: without this the compiler sinks the sum there and
+        // keeps the S normals alive (in scratch) across every evaluation
+        asm volatile("" : "+v"(k0));
+        buf_store(rs_k0(), vo_k0, 0u, k0);
         if (MASS) tri_apply<NT, false>(pr.chM + lane, p, ch.ks); // p0 = chM xi, :80-81
         T::load_state(ch.grad, ch.ld, c, g, gr);
 #pragma unroll
@@ -641,15 +662,19 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
         double k1 = 0.0;
 #pragma unroll
         for (int s = 0; s < S; ++s) k1 += p[s] * p[s];
+        asm volatile("" ::: "memory");
+        k0 = buf_load(rs_k0(), vo_k0, 0u);
+        if (LPMEM) lp = buf_load(rs_lp(), vo_lp, 0u);
         const double logq = 0.5 * (sum4(k1) - sum4(k0)); // :89
         const double u = T::accept_uniform(rng, g, cl);
         if (PT) lpp = combine_post(parts[0], beta * parts[1]); // TemperedModel, ptsampler.py:35-39
-        bool acc_ok = mh_accept(lpp, lp, logq, u);
+        bool acc_ok = mh_accept<true>(lpp, lp, logq, u);
         if (PT) acc_ok = acc_ok && pt_valid && !pt_init && !pt_partner;
         if (acc_ok) {
             if (active) {
                 T::store_state(ch.theta, ch.ld, c, g, q);
                 T::store_state(ch.grad, ch.ld, c, g, gr);
+                if (LPMEM && g == 0) buf_store(rs_lp(), vo_lp, 0u, lpp);
             }
             lp = lpp;
         }
@@ -687,12 +712,12 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
             code = swapper ? (sw_ok ? 3 : 2) : code;
         }
         if (ADAPT) ad.adapt(acc_ok, ch.adapt_target);
-        if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = (uint8_t)code;
+        if (run.h_accept && active && g == 0) buf_store_u8(run.h_accept + t * ch.ld, ch.ld, (uint32_t)c, (uint8_t)code);
     }
     if (active) {
-        if (g == 0) ch.logpost[c] = lp;
+        if (!LPMEM && g == 0) ch.logpost[c] = lp;
         if (ADAPT && g == 0) ad.store(ch, c);
-        xo_store(ch.rng, ch.nslots, slot, rng);
+        xo_store_buf(ch.rng, ch.nslots, slot, rng);
     }
 }
 

@@ -114,9 +114,11 @@ def test_model_base_log_posterior_guard():
 
 
 def test_dpp_hazard_scanner_and_built_kernels():
-    """The hand-written v_fmac_f64_dpp of the tail rows (rmh_run.hpp) must not read a VGPR through
-    DPP within two wait states of a VALU write; the compiler does not check inside inline asm.
-    Compiles the Gaussian translation unit to assembly (no GPU needed) and scans it."""
+    """The hand-written v_fmac_f64_dpp (tail rows of rmh_run.hpp, gradient tail of rmh_models.hpp) must
+    not read a VGPR through DPP within two wait states of a VALU write, nor follow a VALU write of
+    EXEC within five; the compiler does not check inside inline asm.  The build scans the
+    disassembly of the objects it links (riemann_amd/build.py); here the scanner itself is
+    checked and the built objects are scanned again (no GPU needed)."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location(
@@ -125,6 +127,8 @@ def test_dpp_hazard_scanner_and_built_kernels():
     chk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(chk)
     fake = """
+	s_nop 0
+	s_nop 0
 	v_mov_b64_e32 v[10:11], v[2:3]
 	v_fmac_f64_dpp v[4:5], v[10:11], v[6:7] row_newbcast:3 row_mask:0xf bank_mask:0xf
 	ds_read_b64 v[20:21], v9
@@ -133,8 +137,27 @@ def test_dpp_hazard_scanner_and_built_kernels():
 	v_add_f64 v[30:31], v[0:1], v[2:3]
 	s_nop 1
 	v_fmac_f64_dpp v[4:5], v[30:31], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf
+	v_permlane16_swap_b32_e32 v40, v41
+	v_fmac_f64_dpp v[4:5], v[40:41], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf
+	v_cmpx_lt_f64_e32 v[0:1], v[2:3]
+	s_nop 3
+	v_fmac_f64_dpp v[4:5], v[50:51], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf
+.LBB0_1:
+	s_nop 0
+	v_fmac_f64_dpp v[4:5], v[50:51], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf
 """
     total, bad = chk.scan(fake)
-    assert total == 3 and len(bad) == 1 and "v_mov_b64" in bad[0]
+    assert total == 6 and len(bad) == 4, bad
+    assert "v_mov_b64" in bad[0] and "v_permlane16_swap" in bad[1] and "EXEC" in bad[2] and "block entry" in bad[3]
+    # branch targets of a disassembly count as block entries
+    dis = """
+0000000000001000 <k>:
+	s_cbranch_scc1 3                                           // 000000001000: BF850003
+	v_add_f64 v[30:31], v[0:1], v[2:3]                         // 000000001004: D2800000 00000000
+	s_nop 1                                                    // 00000000100C: BF800001
+	v_fmac_f64_dpp v[4:5], v[30:31], v[6:7] row_newbcast:1 row_mask:0xf bank_mask:0xf// 000000001010: 0808A4FA FF01511E
+"""
+    total, bad = chk.scan(dis)
+    assert total == 1 and len(bad) == 1 and "block entry" in bad[0], bad
     total, bad = chk.main()
     assert total >= 600 and not bad, bad

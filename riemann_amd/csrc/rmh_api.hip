@@ -143,6 +143,24 @@ int sync_proposal(rmh_proposal *p)
         }
         RMH_HIP(hipMemcpy(p->d_Ltail, lt.data(), lt.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    // diagonal L (e.g. the block proposal of riemann/test_changepoint.py:36-38 as one matrix):
+    // the proposal is an axpy per coordinate, no matrix product (k_cp_rw_ss)
+    p->L_is_diag = p->kind == kRW;
+    for (int i = 0; i < p->d && p->L_is_diag; ++i)
+        for (int j = 0; j < i; ++j)
+            if (p->L[(size_t)i * p->d + j] != 0.0) {
+                p->L_is_diag = false;
+                break;
+            }
+    if (p->L_is_diag) {
+        std::vector<double> dg((size_t)p->d);
+        for (int i = 0; i < p->d; ++i) dg[i] = sc * p->L[(size_t)i * p->d + i];
+        if (!p->d_Ldiag) {
+            int rc = dev_alloc(&p->d_Ldiag, dg.size());
+            if (rc) return rc;
+        }
+        RMH_HIP(hipMemcpy(p->d_Ldiag, dg.data(), dg.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     p->dirty = false;
     return RMH_OK;
 }
@@ -547,6 +565,40 @@ int rmh_model_changepoint_create(const double *x, const double *y, int n, int k,
     a.c_s = std::lgamma(2 * kp + 1);                      // :143
     a.c_sL = kp * std::log(xmax - xmin);
     a.nlog2pi = n * std::log(2 * M_PI);                   // :119
+    // sufficient statistics for k_cp_rw_ss: with x sorted, the data of piece p are a contiguous
+    // run, so sum (ypred - y)^2 needs only the run boundaries (searches) and prefix sums of y
+    a.ss_xp = nullptr;
+    a.ss_steps = 0;
+    if (n <= 2047) {
+        int steps = 1;
+        while ((2 << (steps - 1)) <= n) ++steps;          // floor(log2 n) + 1
+        const int np = (1 << steps) - 1;                  // >= n
+        std::vector<int> ord((size_t)n);
+        for (int i = 0; i < n; ++i) ord[i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](int u, int v) { return x[u] < x[v]; });
+        double ym = 0.0;
+        for (int i = 0; i < n; ++i) ym += y[i];
+        ym /= n;
+        std::vector<double> xp((size_t)np + (np + 1), 0.0);
+        double p1 = 0.0, p2 = 0.0;
+        for (int i = 0; i < np; ++i) xp[i] = i < n ? x[ord[i]] : HUGE_VAL;
+        for (int i = 0; i <= np; ++i) {
+            xp[(size_t)np + i] = p1;                      // P1[i] = sum of the first i centred y
+            if (i < n) {
+                const double yc = y[ord[i]] - ym;
+                p1 += yc;
+                p2 += yc * yc;
+            }
+        }
+        if ((rc = upload(&m->d_ssxp, xp.data(), xp.size()))) {
+            rmh_model_free(m);
+            return rc;
+        }
+        a.ss_xp = m->d_ssxp;
+        a.ss_steps = steps;
+        a.ss_ym = ym;
+        a.ss_p2 = p2;
+    }
     *out = m;
     return RMH_OK;
 }
@@ -611,6 +663,7 @@ int rmh_model_free(rmh_model_t m)
     (void)hipFree(m->d_Wtail);
     (void)hipFree(m->d_X);
     (void)hipFree(m->d_xy);
+    (void)hipFree(m->d_ssxp);
     (void)hipFree(m->d_ktab);
     (void)hipFree(m->d_mixW);
     (void)hipFree(m->d_mixWT);
@@ -830,6 +883,7 @@ int rmh_proposal_free(rmh_proposal_t p)
     if (!p) return RMH_OK;
     (void)hipFree(p->d_Ltiles);
     (void)hipFree(p->d_Ltail);
+    (void)hipFree(p->d_Ldiag);
     (void)hipFree(p->d_chM);
     (void)hipFree(p->d_V);
     (void)hipFree(p->d_VT);

@@ -60,6 +60,16 @@ RMH_DEV uint64_t xo_next(Xo &x)
     return r;
 }
 
+// the next word of the stream on the lanes where `own` holds (the stream advances there only);
+// an unspecified word elsewhere
+RMH_DEV uint64_t xo_next_if(Xo &x, bool own)
+{
+    Xo tmp = x;
+    const uint64_t r = xo_next(tmp);
+    if (own) x = tmp;
+    return r;
+}
+
 // rng state in global memory: word w of stream (chain c, group g) lives at
 // rng[w * 4*Npad + (c/16)*64 + g*16 + c%16]  (one coalesced 512-B row per wave)
 RMH_DEV int64_t rng_slot(int64_t c, int g) { return (c >> 4) * 64 + g * 16 + (c & 15); }
@@ -149,6 +159,17 @@ RMH_DEV double log_full(double x)
         else if (x == 0.0) r = -inf;
         else r = x; // +inf
     }
+    return r;
+}
+
+// log_full with the specials off the hot path: positive normal finite arguments (all but
+// measure zero of what the samplers feed it) take log_core only; anything else sends the WAVE
+// through log_full once (a wave-uniform, rarely taken branch instead of a dozen selects per call).
+RMH_DEV double log_fast(double x)
+{
+    const bool ok = (x >= 2.2250738585072014e-308) && (x < __builtin_huge_val());
+    double r = log_core(ok ? x : 1.0, 0);
+    if (__builtin_expect(__any(!ok), 0)) r = ok ? r : log_full(x);
     return r;
 }
 

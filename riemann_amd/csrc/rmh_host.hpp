@@ -25,7 +25,7 @@ struct rmh_model {
     rmh::LogRegArgs la{};
     // changepoint
     int k = 0;
-    double *d_xy = nullptr;
+    double *d_xy = nullptr, *d_ssxp = nullptr;
     rmh::CpArgs ca{};
     // changepoint with a variable number of changepoints (capacity k): table by pieces
     double *d_ktab = nullptr;
@@ -43,6 +43,8 @@ struct rmh_proposal {
     std::vector<double> L;     // host copy of the Cholesky factor
     double *d_Ltiles = nullptr;
     double *d_Ltail = nullptr;  // rows 96.. of scale*L for k_run_rw_tail (d = 97..100), or null
+    double *d_Ldiag = nullptr;  // diagonal of scale*L when L is diagonal (k_cp_rw_ss)
+    bool L_is_diag = false;
     bool dirty = true;
     double *d_chM = nullptr, *d_V = nullptr, *d_VT = nullptr; // mass-matrix tile images (HMC)
     double minv = 1.0;                                        // M^-1 = minv (chM chM^T)^-1

@@ -54,6 +54,12 @@ struct CpArgs {
     double c_s;            // lgamma(2k'+1)
     double c_sL;           // k' log(xmax-xmin)
     double nlog2pi;        // n log(2 pi)
+    // sufficient statistics of the likelihood (k_cp_rw_ss, rmh_kernels_cp.hip): x sorted and
+    // padded with +inf to 2^ss_steps - 1 entries, then the prefix sums P1[j] = sum_{i<j} (y_i - ym)
+    // of the y in that order (2^ss_steps entries); null when n is too large for the LDS
+    const double *ss_xp;
+    int ss_steps;          // steps of the branch-free upper-bound search: floor(log2 n) + 1
+    double ss_ym, ss_p2;   // mean of y, sum (y_i - ym)^2
 };
 
 // Trans-dimensional changepoint sampling: model with a variable number
@@ -107,6 +113,7 @@ struct RwArgs {
     int nblk;
     int blk_end[3];
     double blk_p[3];
+    const double *Ldiag;  // the diagonal of scale*L when L is diagonal (d entries), else null
 };
 
 struct HmcArgs {
@@ -184,6 +191,9 @@ hipError_t launch_cp_eval(int k, const CpArgs &m, const ChainArgs &c, double *lp
                           double *llik, double *lpost, hipStream_t st);
 hipError_t launch_cp_rw(int k, const CpArgs &m, const RwArgs &p, const ChainArgs &c,
                         const RunArgs &r, hipStream_t st);
+// sufficient-statistics kernel (diagonal proposal, alpha = 1, plain random walk)
+hipError_t launch_cp_rw_ss(int k, const CpArgs &m, const RwArgs &p, const ChainArgs &c,
+                           const RunArgs &r, hipStream_t st);
 
 // device-side covariance update of the pooled AdaptCov (k_acov_update, rmh_kernels_mfma.hip)
 struct AcovUpdateArgs {

@@ -314,6 +314,216 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs
     xo_store(ch.rng, ch.nslots, slot, rng);
 }
 
+// ------------------------------------------------------------------------------------------
+// BASELINE cfg 5 proper: plain random walk with a DIAGONAL proposal factor (the block proposal of
+// riemann/test_changepoint.py:36-38 written as one matrix) and alpha = 1.  Same sampler, same
+// stream, same accept rule as k_cp_rw; what changes is where the arithmetic of an iteration goes:
+//   * likelihood from sufficient statistics.  k_cp_rw spends O(n) compare/select/fma steps per
+//     chain and iteration on sum_i (ypred_i - y_i)^2 (changepoint.py:181, :118).  The data are fixed:
+//     with x sorted once (host), the data of piece p are the run [B_{p-1}, B_p) with
+//     B_p = #{i : x_i <= cpx_p} (searchsorted side='left' of predict, :181, seen from the data's
+//     side), and with P1 = prefix sums of y - ym
+//         sum_i (ypred_i - y_i)^2 = sum (y_i - ym)^2 + sum_p vc_p (m_p vc_p - 2 (P1[B_p] - P1[B_{p-1}])),
+//     vc_p = cpv_p - ym, m_p = B_p - B_{p-1}: k branch-free binary searches of floor(log2 n) + 1
+//     steps (x padded with +inf to 2^steps - 1 entries in LDS) instead of n predictions.  Centring
+//     by ym keeps the cancellation harmless (the sums are O(n var y), not O(n y^2)).
+//   * the chain's four lanes share the work through LDS, not through register selects: lane g
+//     owns coordinates g, 4+g, 8+g (.. the B-operand layout of the stream), proposes them with one
+//     fma each (diagonal factor: no matrix product), writes them to a per-wave LDS row and every
+//     lane reads the whole candidate back; lane g searches boundary g (and 4+g), the lanes publish
+//     (B, P1[B]) pairs the same way.  The cross-lane traffic costs LDS instructions, which the
+//     four resident waves per SIMD cover, instead of VALU issue slots (k_cp_rw: three all-gathers
+//     by row swaps, ~170 cycles, plus ~90 v_cndmask of static-index selects per iteration).
+//   * prior (changepoint.py:128-160) with alpha = 1: (alpha-1) log(cpv) is 0 for cpv > 0 and NaN
+//     otherwise, exactly as numpy evaluates it, so no logarithm per height; sum_j log(ds_j) =
+//     log(prod_j ds_j) guarded by min_j ds_j > 0 (two negative gaps must not cancel); log(1/sig^2)
+//     = -log(sig^2), which the likelihood needs anyway: two logarithms per iteration instead of six.
+// The sums are formed in another order than numpy's, so log densities agree with the oracle to
+// rounding (1e-13 observed, 1e-9 asserted), not bit for bit; accept masks agree exactly on every
+// fixture and comparison run.
+template <int KC>
+__global__ void __launch_bounds__(512, 4) k_cp_rw_ss(CpArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
+{
+    constexpr int D = 2 * KC + 2, KP = KC + 1;
+    constexpr int NT = (D + 15) / 16, S = 4 * NT; // the lane owns coordinates 4s + g
+    constexpr int NS = (D + 3) / 4;              // k-steps that hold coordinates
+    constexpr int TS = 2 * (((D + 1) / 2) | 1);  // doubles per chain row of the candidate exchange (an odd
+                                                 // number of 16-byte units: the 16 chains' reads fall on disjoint banks)
+    constexpr int BS = 2 * (KC | 1);             // doubles per chain row of the (B, P1[B]) exchange
+    using T = Tile<NT>;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int np = (1 << m.ss_steps) - 1;        // padded x entries; P1 has np + 1
+    double *xs = lds, *P1 = lds + np;
+    double *tab = P1 + np + 2;                   // 2 np + 2 doubles: the table and the rows stay 16-byte aligned
+    double *xch = tab + kIcdfDoubles;            // per wave: 16 x TS candidate rows, 16 x BS boundary rows
+    for (int i = threadIdx.x; i < 2 * np + 1; i += blockDim.x) lds[i] = m.ss_xp[i];
+    icdf_stage(tab, ch.icdf);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, g = lane >> 4;
+    const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (blk >= ch.nblocks) return;
+    const int64_t c = blk * 16 + cl, slot = blk * 64 + lane;
+    double *trow = xch + wave * (16 * (TS + BS)) + cl * TS;
+    double *brow = xch + wave * (16 * (TS + BS)) + 16 * TS + cl * BS;
+
+    // this lane's coordinates 4s + g of the current state and of the proposal factor
+    double th[NS], ld[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bool in = 4 * s + g < D;
+        th[s] = in ? ch.theta[(int64_t)(4 * s + g) * ch.ld + c] : 0.0;
+        ld[s] = in ? pr.Ldiag[4 * s + g] : 0.0;
+    }
+    double lp = ch.logpost[c];
+    Xo rng = xo_load(ch.rng, ch.nslots, slot);
+
+    int64_t knext = run.nburn, kentry = 0;
+    const uint32_t hvoff = (uint32_t)((int64_t)g * ch.ld + c) * 8u, hrow = (uint32_t)ch.ld * 32u;
+    auto rec = [&](int64_t e) {
+        if (e != knext) return;
+        knext += run.nthin;
+        const int64_t k = kentry++;
+        if (!run.h_theta) return;
+        const __amdgpu_buffer_rsrc_t r =
+            rsrc(run.h_theta + k * (int64_t)(4 * ch.ks) * ch.ld, (int64_t)(4 * ch.ks) * ch.ld);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (4 * s + g < D) buf_store(r, hvoff, hrow * (uint32_t)s, th[s]);   // rows 4s + g: the history layout
+        if (g == 0) buf_store(rsrc(run.h_logpost + k * ch.ld, ch.ld), (uint32_t)c * 8u, 0u, lp);
+    };
+    rec(0);
+
+    const double kpc = (double)KP * (m.c_v - m.lgam_alpha);   // alpha = 1: sum_j (alpha log beta - lgamma(alpha))
+    for (int64_t t = 0; t < run.T; ++t) {
+        asm volatile("" ::: "memory");
+        // ---- propose: theta' = theta + scale L xi, L diagonal (randomwalk.py:26)
+        double xi[S];
+        T::template normals_fixed<(D + 7) / 8, D, 1>(rng, D, g, tab, xi);
+        double tp[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            tp[s] = fma_(ld[s], xi[s], th[s]);
+            if (4 * s + g < D) trow[4 * s + g] = tp[s];
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's own LDS writes are in order
+        double cand[2 * ((D + 1) / 2)];
+#pragma unroll
+        for (int q = 0; q < (D + 1) / 2; ++q) {
+            const d2_t v = reinterpret_cast<const d2_t *>(trow - 0)[q];
+            cand[2 * q] = v.x;
+            cand[2 * q + 1] = v.y;
+        }
+        // ---- prior (changepoint.py:128-160), every lane for itself
+        double prod = 1.0, dmin = __builtin_huge_val(), vsum = 0.0, vmin = __builtin_huge_val();
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const double lo = (j == 0) ? m.xmin : cand[j - 1 < 0 ? 0 : j - 1];
+            const double hi = (j == KC) ? m.xmax : cand[j < KC ? j : 0];
+            const double dx = hi - lo;                            // s[1:] - s[:-1], :142-143
+            prod *= dx;
+            dmin = __builtin_fmin(dmin, dx);                      // (a NaN gap leaves dmin alone and poisons prod)
+            const double v = cand[KC + j];
+            vsum += v;
+            vmin = __builtin_fmin(vmin, v);
+        }
+        const double nan = __builtin_nan("");
+        const double sig = cand[D - 1], sig2 = sig * sig;
+        // The iteration's three logarithms -- log(u) of the accept test (sampler.py:84), log(prod ds)
+        // and log(sig^2) -- are ONE evaluation: lane group 0 (the owner of the accept uniform's
+        // sub-stream) takes u, group 1 the product, group 2 sig^2, and an all-gather over the chain's
+        // four lanes hands every lane the three results.  log_fast is log_core, operation for
+        // operation the accept test's logarithm, for every positive normal argument.
+        const double uown = u01(xo_next_if(rng, g == 0));
+        const double larg = g == 0 ? uown : g == 1 ? prod : g == 2 ? sig2 : 1.0;
+        double lg[4];
+        gather4(log_fast(larg), lg);
+        const double lu = lg[0], lsig2 = lg[2];
+        const double ps = (dmin > 0.0) ? lg[1] : (dmin == 0.0 ? -__builtin_huge_val() : nan);
+        const double pv = (vmin > 0.0) ? fma_(-m.beta, vsum, kpc) : nan;     // :19 with alpha = 1
+        const double p2 = (sig < 0.0) ? nan : -lsig2;                        // :145-147
+        double logP = ((m.c_k + pv) + ((m.c_s + ps) - m.c_sL)) + p2;         // :156
+        if (logP != logP) logP = -__builtin_huge_val();                      // :158-159
+        double lpp = -__builtin_huge_val();
+        if (__any(logP > -__builtin_huge_val())) {
+            // ---- likelihood: lane g searches B_j = #{x <= cpx'_j} for j = g (and 4 + g)
+#pragma unroll
+            for (int jj = 0; jj < (KC + 3) / 4; ++jj) {
+                const int j = 4 * jj + g;
+                if (j < KC) {
+                    const double key = trow[j];
+                    int lo8 = 0;                                  // 8 * (entries known to be <= key)
+                    for (int st = m.ss_steps - 1; st >= 0; --st) {
+                        const int step8 = 8 << st;
+                        const double xv = *reinterpret_cast<const double *>(
+                            reinterpret_cast<const char *>(xs) + lo8 + step8 - 8);
+                        lo8 += (xv <= key) ? step8 : 0;
+                    }
+                    const double p1 = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(P1) + lo8);
+                    d2_t pair;
+                    pair.x = (double)(lo8 >> 3);
+                    pair.y = p1;
+                    reinterpret_cast<d2_t *>(brow)[j] = pair;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double acc = 0.0, bprev = 0.0, pprev = 0.0;
+#pragma unroll
+            for (int pz = 0; pz < KP; ++pz) {
+                double bcur = (double)m.n, pcur = 0.0;            // P1[n] = 0 up to rounding: the y are centred
+                if (pz < KC) {
+                    const d2_t pair = reinterpret_cast<const d2_t *>(brow)[pz];
+                    bcur = pair.x;
+                    pcur = pair.y;
+                } else {
+                    pcur = P1[m.n];
+                }
+                const double vc = cand[KC + pz] - m.ss_ym;
+                acc = fma_(vc, fma_(bcur - bprev, vc, -2.0 * (pcur - pprev)), acc);
+                bprev = bcur;
+                pprev = pcur;
+            }
+            const double ss = (m.ss_p2 + acc) / sig2;
+            double logL = -0.5 * ((ss + m.n * lsig2) + m.nlog2pi);            // :118-121
+            if (logL != logL) logL = -__builtin_huge_val();                   // :124-125
+            lpp = combine_post(logP, logL);                                   // model.py:49-55
+        }
+        // Sampler.sample, sampler.py:83-84 (mh_accept with the logarithm taken above; log(0) = -inf)
+        const double delta = lpp - lp - 0.0;
+        const bool ok = lu < ((delta < 0.0) ? delta : 0.0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) th[s] = ok ? tp[s] : th[s];
+        lp = ok ? lpp : lp;
+        if (run.h_accept && g == 0) run.h_accept[t * ch.ld + c] = ok ? 1 : 0;
+        rec(t + 1);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (4 * s + g < D) ch.theta[(int64_t)(4 * s + g) * ch.ld + c] = th[s];
+    if (g == 0) ch.logpost[c] = lp;
+    xo_store(ch.rng, ch.nslots, slot, rng);
+}
+
+template <int KC>
+static hipError_t cp_rw_ss_launch(const CpArgs &m, const RwArgs &p, const ChainArgs &c,
+                                  const RunArgs &r, hipStream_t st)
+{
+    constexpr int D = 2 * KC + 2, TS = 2 * (((D + 1) / 2) | 1), BS = 2 * (KC | 1);
+    const int nw = 8, np = (1 << m.ss_steps) - 1;
+    const size_t lds = sizeof(double) * ((size_t)2 * np + 2 + kIcdfDoubles + (size_t)nw * 16 * (TS + BS));
+    if (lds > 80 * 1024) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((c.nblocks + nw - 1) / nw));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cp_rw_ss<KC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_cp_rw_ss<KC>, grid, dim3(64 * nw), lds, st, m, p, c, r);
+    return hipGetLastError();
+}
+
 // Model.log_prior / log_likelihood / log_posterior for the states in ch.theta
 template <int KC>
 __global__ void __launch_bounds__(256) k_cp_eval(CpArgs m, ChainArgs ch, double *lprior,
@@ -710,6 +920,12 @@ hipError_t launch_cp_rw(int k, const CpArgs &m, const RwArgs &p, const ChainArgs
                         const RunArgs &r, hipStream_t st)
 {
     RMH_CP_DISPATCH(cp_rw_launch, m, p, c, r, st)
+}
+
+hipError_t launch_cp_rw_ss(int k, const CpArgs &m, const RwArgs &p, const ChainArgs &c,
+                           const RunArgs &r, hipStream_t st)
+{
+    RMH_CP_DISPATCH(cp_rw_ss_launch, m, p, c, r, st)
 }
 
 // the generic fused kernels over the changepoint policy: variant 1 = AdaptScale random walk,

@@ -1,0 +1,121 @@
+"""Full-size property tests of BASELINE.json configs 3, 4 and 5: 65 536 chains per GPU (the size
+bench.py measures) on the benchmark's own data, through size-independent properties --
+  (i)   a shard started with chain0 = a equals chains [a, b) of the whole job, bit for bit
+        (the multi-GPU partition is exact);
+  (ii)  run(a) + run(b) == run(a + b), with and without a recorded history;
+  (iii) thinning keeps every Nthin-th state --
+plus oracle comparisons with every wave of a workgroup live at n = 10 000 (512 chains: the
+8-waves-per-workgroup staging of X streams 313 stages past eight waves).  cfg2's twin is
+test_gpu_parity.py::test_full_size_sharding_and_resume_invariance."""
+import numpy as np
+import pytest
+
+from gpu_common import RTOL, oracle_run
+
+pytestmark = pytest.mark.gpu
+
+N = 65536
+
+
+def _properties(ra, make, T1, T2, thin, shard=(16384, 32768)):
+    """make() -> (model, proposal, theta0 (N, d)); the proposal object is shared by the samplers."""
+    m, p, th0 = make()
+    whole = ra.Sampler(m, p, th0, seed=1)
+    whole.run(T1 + T2)
+    th_w, lp_w = whole.current_state()
+    acc_w = whole._chain_accept.copy()
+    hist_w = whole._chain_thetas[T1::thin].copy() if T2 % thin == 0 else None
+    del whole
+    a, b = shard
+    part = ra.Sampler(m, p, th0[a:b], seed=1, chain0=a)
+    part.run(T1 + T2)
+    th_s, lp_s = part.current_state()
+    np.testing.assert_array_equal(th_s, th_w[a:b])
+    np.testing.assert_array_equal(lp_s, lp_w[a:b])
+    np.testing.assert_array_equal(part._chain_accept, acc_w[:, a:b])
+    del part
+    two = ra.Sampler(m, p, th0, seed=1)
+    two.run(T1, record=False)
+    two.run(T2, 0, thin)
+    th_t, lp_t = two.current_state()
+    np.testing.assert_array_equal(th_t, th_w)
+    np.testing.assert_array_equal(lp_t, lp_w)
+    if hist_w is not None:
+        np.testing.assert_array_equal(two._chain_thetas, hist_w)
+    return acc_w
+
+
+def _logreg(eps, L):
+    from riemann_amd.models import LogisticRegression
+    from riemann_amd.proposals import MALA, VanillaHMC
+    from riemann_amd.workloads import logreg_data
+    X, y = logreg_data(10000, 100, seed=2)
+    m = LogisticRegression(X, y, 100.0)
+    th0 = 0.02 * np.random.default_rng(3).standard_normal((N, 100))
+    return m, (MALA(eps, m) if L == 1 else VanillaHMC(eps, L, m)), th0
+
+
+def test_cfg3_logistic_mala_full_size_properties(ra):
+    acc = _properties(ra, lambda: _logreg(0.175, 1), 6, 6, 3)
+    assert 0.3 < acc.mean() < 0.9
+
+
+def test_cfg4_logistic_hmc_full_size_properties(ra):
+    acc = _properties(ra, lambda: _logreg(0.10, 10), 1, 2, 1)
+    assert 0.3 < acc.mean() <= 1.0
+
+
+def test_cfg5_changepoint_full_size_properties(ra):
+    from riemann_amd.models import ChangepointRegression1D
+    from riemann_amd.proposals import MetropolisRandomWalk
+    from riemann_amd.workloads import changepoint_data
+
+    def make():
+        x, y, truth, cdiag = changepoint_data()
+        th0 = truth + 0.01 * np.random.default_rng(5).standard_normal((N, 12))
+        th0[:, :5] = np.sort(th0[:, :5], axis=1)
+        p = MetropolisRandomWalk(np.diag(cdiag))
+        p.scale = 0.1
+        return ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=5), p, th0
+
+    acc = _properties(ra, make, 120, 90, 3)
+    assert 0.05 < acc.mean() < 0.9
+
+
+@pytest.mark.parametrize("L,eps,T", [(1, 0.175, 5), (4, 0.12, 2)])
+def test_logistic_10000x100_vs_oracle_with_eight_live_waves(ra, orc, L, eps, T):
+    """512 chains = four full workgroups of eight waves on the cfg3/cfg4 data against the oracle."""
+    from riemann_amd.models import LogisticRegression
+    from riemann_amd.proposals import MALA, VanillaHMC
+    from riemann_amd.workloads import logreg_data
+    X, y = logreg_data(10000, 100, seed=2)
+    m = LogisticRegression(X, y, 100.0)
+    th0 = 0.02 * np.random.default_rng(9).standard_normal((512, 100))
+    s = ra.Sampler(m, MALA(eps, m) if L == 1 else VanillaHMC(eps, L, m), th0, seed=4)
+    s.run(T)
+    ht, hl, acc = oracle_run(orc, orc.LogReg(X, y, 100.0), orc.HMC(eps, L, 100), th0, 4, T)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(s._chain_logpost, hl, rtol=RTOL)
+
+
+def test_cfg5_changepoint_16384_chains_vs_oracle(ra, orc):
+    """The sufficient-statistics kernel on the cfg5 data against the oracle's O(n) likelihood."""
+    from riemann_amd.models import ChangepointRegression1D
+    from riemann_amd.proposals import MetropolisRandomWalk
+    from riemann_amd.workloads import changepoint_data
+    x, y, truth, cdiag = changepoint_data()
+    n = 16384
+    th0 = truth + 0.01 * np.random.default_rng(5).standard_normal((n, 12))
+    th0[:, :5] = np.sort(th0[:, :5], axis=1)
+    p = MetropolisRandomWalk(np.diag(cdiag))
+    p.scale = 0.1
+    s = ra.Sampler(ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=5), p, th0, seed=6)
+    s.run(100)
+    ht, hl, acc = oracle_run(orc, orc.Changepoint(x, y, 5, 1.0, 3.0, 5.0, 1.0, 1.0),
+                             orc.RandomWalk(np.diag(cdiag), 0.1), th0, 6, 100)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    fin = np.isfinite(hl)
+    assert np.array_equal(np.isfinite(s._chain_logpost), fin)
+    np.testing.assert_allclose(s._chain_logpost[fin], hl[fin], rtol=RTOL)

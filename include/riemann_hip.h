@@ -162,6 +162,14 @@ int rmh_proposal_free(rmh_proposal_t p);
  * theta_p (N,d), logqratio (N).  rng (N,16) uint64 is advanced in place. */
 int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
                 uint64_t *rng, double *theta_p, double *logq);
+/* The draws of T iterations of Sampler.sample for N chains from the host copy of their stream
+ * state ((N,16) uint64, advanced in place): per iteration the d standard normals of
+ * proposals/randomwalk.py:25 / proposals/hamiltonian.py:79 (xi, (T,N,d); d = 0: none, xi may be
+ * null) and the accept uniform of samplers/sampler.py:84 (u, (T,N); null: the normals only and
+ * the uniform's word is NOT drawn), in the order and with the bits the fused kernels use.  For the mixed-plugin path: a Python Model or Proposal next to
+ * device ones runs sampler.py:72-90 on the host with THIS stream. */
+int rmh_rng_draw(uint64_t *rng, int64_t N, int d, int T, double *xi, double *u);
+
 
 /* ---- chain state (device resident; survives between run() calls as the
  *      history lists do, samplers/sampler.py:49-50) ------------------------ */

@@ -56,6 +56,7 @@ SIGNATURES = {
     "rmh_proposal_set_adapt": [_vp, _dbl],
     "rmh_proposal_free": [_vp],
     "rmh_propose": [_vp, _vp, _f64, _i64, _u64, _f64, _f64],
+    "rmh_rng_draw": [_u64, _i64, _int, _int, _vp, _vp],
     "rmh_state_create": [_vp, _i64, _u64s, _u64s, _pvp],
     "rmh_state_set_theta": [_vp, _f64],
     "rmh_state_get": [_vp, _vp, _vp],

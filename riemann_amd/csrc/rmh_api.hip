@@ -1280,6 +1280,41 @@ int rmh_history_free(rmh_history_t h)
 
 extern "C" {
 
+// The stream of a chain for callers that run part of Sampler.sample on the host (a Python Model
+// or Proposal plugin next to device ones, samplers/sampler.py of this package): T iterations'
+// worth of draws -- d normals (randomwalk.py:25 / hamiltonian.py:79), then the accept uniform
+// (sampler.py:84) -- exactly as the fused kernels consume them.  d = 0: the uniforms only.
+int rmh_rng_draw(uint64_t *rng, int64_t N, int d, int T, double *xi, double *u)
+{
+    RMH_NEED_INIT();
+    if (!rng || N < 1 || d < 0 || T < 1 || (d > 0 && !xi) || (d == 0 && !u))
+        return fail(RMH_ERR_PARAM, "rng_draw: bad argument");
+    const int64_t ld = pad16(N);
+    std::vector<uint64_t> dev;
+    rng_to_device_layout(rng, N, ld, dev);
+    uint64_t *drng = nullptr;
+    double *dxi = nullptr, *du = nullptr;
+    int rc;
+    if ((rc = upload(&drng, dev.data(), dev.size())) || (rc = dev_alloc(&dxi, (size_t)T * ld * (d > 0 ? d : 1))) ||
+        (u && (rc = dev_alloc(&du, (size_t)T * ld)))) {
+        (void)hipFree(drng); (void)hipFree(dxi); (void)hipFree(du);
+        return rc;
+    }
+    hipError_t e = launch_rng_stream(drng, ld, d, T, g_icdf, dxi, du, g_stream);
+    if (e == hipSuccess && d > 0)
+        e = hipMemcpy2DAsync(xi, (size_t)N * d * 8, dxi, (size_t)ld * d * 8, (size_t)N * d * 8, (size_t)T,
+                             hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess && u)
+        e = hipMemcpy2DAsync(u, (size_t)N * 8, du, (size_t)ld * 8, (size_t)N * 8, (size_t)T,
+                             hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dev.data(), drng, dev.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    (void)hipFree(drng); (void)hipFree(dxi); (void)hipFree(du);
+    RMH_HIP(e);
+    rng_from_device_layout(dev, N, ld, rng);
+    return RMH_OK;
+}
+
 // --------------------------------------------------------------- test hooks
 int rmh_debug_rng_stream(uint64_t seed, uint64_t chain0, int64_t N, int d, int T, double *xi, double *u)
 {

@@ -345,8 +345,10 @@ __global__ void k_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const doub
             if (8 * m + g < d) xi[((int64_t)t * ld + c) * d + 8 * m + g] = zh;
             if (8 * m + 4 + g < d) xi[((int64_t)t * ld + c) * d + 8 * m + 4 + g] = zl;
         }
-        const double uu = Tile<1>::accept_uniform(x, g, cl);
-        if (g == 0) u[(int64_t)t * ld + c] = uu;
+        if (u) { // null: the normals only
+            const double uu = Tile<1>::accept_uniform(x, g, cl);
+            if (g == 0) u[(int64_t)t * ld + c] = uu;
+        }
     }
     xo_store(rng, nslots, slot, x);
 }

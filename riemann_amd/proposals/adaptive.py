@@ -17,6 +17,9 @@ class AdaptScaleProposal(DeviceProposal):
     per chain (scalars for a single chain)."""
 
     def _init_adapt(self, target_accept_rate):
+        if not self._h:
+            raise TypeError("the adaptive device proposals need a device Model (their adaptation state "
+                            "lives with the chains on the GPU)")
         self.Nsamples = 0
         self.Naccepts = 0
         self.last_theta = None
@@ -38,7 +41,7 @@ class AdaptScaleProposal(DeviceProposal):
         else:
             self.Nsamples, self.Naccepts, self.scale, self.accept_rate = ns, na, sc, rate
 
-    def propose(self, theta):
+    def propose(self, theta, rng=None):
         raise NotImplementedError("stand-alone propose() of an adaptive proposal is not built: "
                                   "the per-chain scale lives with the Sampler's chains")
 

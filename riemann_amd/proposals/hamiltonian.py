@@ -1,10 +1,13 @@
-"""VanillaHMC / MALA on the device: /root/reference/riemann/proposals/hamiltonian.py:13-91.
+"""VanillaHMC / MALA: /root/reference/riemann/proposals/hamiltonian.py:13-91.
 
-The reference takes an arbitrary Python callable for the gradient
-(hamiltonian.py:60-70).  Here the gradient must come from a device Model, so
-``gradlogpost`` is either that Model or one of its bound gradient methods
-(``model.grad_log_posterior`` / ``model.grad_log_likelihood``), which is how
-the reference's own example passes it (examples/test_randomwalk.py:32-37).
+``gradlogpost`` is (i) a device Model or one of its bound gradient methods
+(``model.grad_log_posterior`` / ``model.grad_log_likelihood``: how the reference's own example
+passes it, examples/test_randomwalk.py:32-37) -- then the whole trajectory is fused with the
+sampler in one kernel -- or (ii) any Python callable ``theta (d,) -> gradient (d,)``
+(hamiltonian.py:60-70), the plugin contract of the reference: the trajectory then runs on the
+host, one callback per leapfrog step, with the momenta drawn from the rmh-rng stream on the
+device (``rmh_rng_draw``).  (ii) is the plugin API for user code, not a CPU twin of the device
+models: a device Model never takes that route.
 Unlike the reference module, importing this one does not import matplotlib."""
 import ctypes as C
 
@@ -20,15 +23,19 @@ class VanillaHMC(DeviceProposal):
     """Leapfrog proposal with identity mass matrix; logqratio = dK
     (hamiltonian.py:76-91).  ``.eps``, ``.Nsteps``, ``.M``, ``.chM`` as in the reference."""
 
-    def __init__(self, eps, Nsteps, gradlogpost, M=None):
+    def __init__(self, eps, Nsteps, gradlogpost, M=None, Npars=None, batched=False):
+        """``Npars``: the dimension, needed only with a Python gradient callable when no ``M``
+        gives it; ``batched``: the callable takes (N, d) and returns (N, d)."""
         model = getattr(gradlogpost, "__self__", gradlogpost)
-        if not isinstance(model, DeviceModel):
-            raise TypeError("VanillaHMC on the MI355X back end needs the gradient of a device "
-                            "Model: pass the Model or its grad_log_posterior method")
         if int(Nsteps) != Nsteps or Nsteps < 1:
             raise _lib.ParameterError("Nsteps must be an integer >= 1")
         self.Nsteps, self.eps = int(Nsteps), eps
         self._mgradU = gradlogpost
+        if not isinstance(model, DeviceModel):
+            if not callable(gradlogpost):
+                raise TypeError("VanillaHMC needs a device Model or a callable gradient (hamiltonian.py:60-70)")
+            self._init_host(gradlogpost, M, Npars, batched)
+            return
         self._model = model
         self.Npars = model.Npars
         h = C.c_void_p()
@@ -45,7 +52,62 @@ class VanillaHMC(DeviceProposal):
             _lib.call("rmh_proposal_hmc_set_mass", self._h, _lib.as_f64(self.chM).ctypes.data)
 
     def _sync(self):
-        _lib.call("rmh_proposal_set_eps", self._h, float(self.eps))
+        if self._h:
+            _lib.call("rmh_proposal_set_eps", self._h, float(self.eps))
+
+    # ---- (ii) Python gradient callable: the trajectory on the host (hamiltonian.py:13-52, 76-91)
+    _host_grad = None
+
+    def _init_host(self, grad, M, Npars, batched):
+        self._host_grad, self._batched = grad, bool(batched)
+        if M is None:
+            self.M = self.chM = None
+            if Npars is not None:
+                self.Npars = int(Npars)
+        else:
+            self.M = np.atleast_2d(np.asarray(M, dtype=np.float64))
+            self.chM = np.linalg.cholesky(self.M)
+            self.Npars = self.M.shape[0]
+
+    def _grad_rows(self, q):
+        if self._batched:
+            return np.asarray(self._host_grad(q), dtype=np.float64)
+        return np.stack([np.asarray(self._host_grad(row), dtype=np.float64) for row in q])
+
+    def _propose_host(self, theta, rng):
+        th = _lib.as_f64(theta)
+        single = th.ndim <= 1
+        q = np.atleast_2d(np.atleast_1d(th)).copy()
+        N, d = q.shape
+        if self.Npars is None:
+            self.Npars = d
+        if d != self.Npars:
+            raise _lib.ParameterError("theta and M have incompatible shapes")
+        p = np.empty((1, N, d))
+        _lib.call("rmh_rng_draw", self._stream(N) if rng is None else rng, N, d, 1, p.ctypes.data, None)
+        p = p[0]                                                   # p ~ N(0, I), hamiltonian.py:79
+        k0 = np.sum(p * p, axis=1)
+        eps = float(self.eps)
+        if self.chM is not None:
+            p = p @ self.chM.T                                     # :80-81
+            minv = lambda v: np.linalg.solve(self.M, v.T).T        # noqa: E731   :29, :36
+        else:
+            minv = lambda v: v                                     # noqa: E731
+        p = p + 0.5 * eps * self._grad_rows(q)                     # leapfrog, :27
+        q = q + eps * minv(p)                                      # :29-30
+        for _ in range(self.Nsteps - 1):                           # :33-37
+            p = p + eps * self._grad_rows(q)
+            q = q + eps * minv(p)
+        p = p + 0.5 * eps * self._grad_rows(q)                     # :40
+        if self.chM is not None:
+            p = np.linalg.solve(self.chM, p.T).T                   # :85-87
+        logq = 0.5 * (np.sum(p * p, axis=1) - k0)                  # :89
+        return (q[0], float(logq[0])) if single else (q, logq)
+
+    def propose(self, theta, rng=None):
+        if self._host_grad is not None:
+            return self._propose_host(theta, rng)
+        return DeviceProposal.propose(self, theta, rng)
 
 
 class MALA(VanillaHMC):
@@ -53,8 +115,8 @@ class MALA(VanillaHMC):
     theta + eps^2/2 grad + eps z, and dK equals the Langevin proposal ratio
     (SURVEY.md 8a-7).  The reference has no such class."""
 
-    def __init__(self, eps, gradlogpost):
-        VanillaHMC.__init__(self, eps, 1, gradlogpost)
+    def __init__(self, eps, gradlogpost, Npars=None, batched=False):
+        VanillaHMC.__init__(self, eps, 1, gradlogpost, Npars=Npars, batched=batched)
 
 
 class AdaptScaleHMC(AdaptScaleProposal, VanillaHMC):

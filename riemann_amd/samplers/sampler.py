@@ -6,9 +6,18 @@ additive:
   * ``theta0`` may be ``(N, d)``: N independent chains (the reference runs one);
   * the random stream is explicit (``seed``, ``chain0``) instead of numpy's
     process-global generator (randomwalk.py:25, sampler.py:84);
-  * ``run`` is ONE fused kernel launch for all chains and all iterations; the
-    history stays on the device until ``_chain_thetas`` / ``_chain_logpost``
-    are read.
+  * with a device Model AND a device Proposal ``run`` is ONE fused kernel launch for all
+    chains and all iterations; the history stays on the device until ``_chain_thetas`` /
+    ``_chain_logpost`` are read.
+
+Mixed plugins ("Batched extension"): the reference samples ANY ``Model`` /
+``Proposal`` subclass (sampler.py:72-90).  When either plugin is the user's own Python class --
+a numpy Model, a Proposal with its own ``propose``, a ``VanillaHMC`` built on a Python gradient
+callable -- the Sampler runs sampler.py:72-90 itself, per iteration: the Proposal's ``propose``
+(device proposals through ``rmh_propose`` on the chains' stream), the Model's ``log_posterior``
+(device Models through ``rmh_log_posterior``), and the accept test with the stream's own uniform
+(``rmh_rng_draw``), so the chain consumes the same stream as the fused path would.  That is the
+plugin API doing what it says, not a CPU fallback: device plugins never take it.
 """
 import ctypes as C
 
@@ -31,12 +40,16 @@ class Sampler(object):
         :param chain0: global id of the first chain (chains of a multi-GPU job
             keep their streams whatever the number of GPUs)
         """
-        if not isinstance(model, DeviceModel) or not isinstance(proposal, DeviceProposal):
-            raise TypeError("riemann_amd.Sampler runs on the GPU: model and proposal must be "
-                            "device plugins (riemann_amd.models / riemann_amd.proposals); "
-                            "there is no CPU sampling path in this package")
+        if not hasattr(model, "log_posterior") or not hasattr(proposal, "propose"):
+            raise TypeError("Sampler needs a Model (log_posterior) and a Proposal (propose)")
         self.model = model
         self.proposal = proposal
+        self._seed, self._chain0 = int(seed), int(chain0)
+        self._state = self._hist = None
+        self.last_run_ms = None
+        if not self._fused():
+            self._init_mixed(theta0)
+            return
         th = model._pack_theta(theta0)
         th = _lib.as_f64(th)
         self._single = th.ndim <= 1
@@ -56,7 +69,77 @@ class Sampler(object):
         self._host_logpost = lp[None].copy()
         self._host_accept = np.zeros((0, self.Nchains), dtype=np.uint8)
         self._kept = 1
-        self.last_run_ms = None
+
+    # ------------------------------------------------------- mixed plugins --
+    def _fused(self):
+        """Both plugins device-backed (and the proposal not a host-gradient HMC): the fused path."""
+        return (isinstance(self.model, DeviceModel) and isinstance(self.proposal, DeviceProposal)
+                and getattr(self.proposal, "_host_grad", None) is None)
+
+    def _init_mixed(self, theta0):
+        from ..rng import rng_seed_host
+        pack = getattr(self.model, "_pack_theta", None)
+        th = _lib.as_f64(pack(theta0) if pack else theta0)
+        self._single = th.ndim <= 1
+        th = np.atleast_2d(np.atleast_1d(th)).copy()
+        self.Nchains, self.Npars = th.shape
+        self._rng = rng_seed_host(self._seed, self.Nchains, self._chain0)
+        self._th, self._lp = th, self._model_lp(th)                      # sampler.py:42
+        self._host_thetas, self._host_logpost = th[None].copy(), self._lp[None].copy()
+        self._host_accept = np.zeros((0, self.Nchains), dtype=np.uint8)
+        self._kept = 1
+
+    def _model_lp(self, th):
+        if isinstance(self.model, DeviceModel):
+            return np.atleast_1d(np.asarray(self.model.log_posterior(th), dtype=np.float64))
+        return np.array([float(self.model.log_posterior(row)) for row in th])
+
+    def _step_mixed(self):
+        """Sampler.sample (sampler.py:72-90) for all chains, plugins called as the reference calls them."""
+        N = self.Nchains
+        if isinstance(self.proposal, DeviceProposal):
+            if hasattr(self.proposal, "_pull_adapt"):
+                raise TypeError("adaptive device proposals need a device Model")
+            thp, logq = self.proposal.propose(self._th, rng=self._rng)            # :79
+            thp, logq = np.atleast_2d(thp), np.atleast_1d(logq)
+        else:
+            out = [self.proposal.propose(row) for row in self._th]
+            thp = np.stack([np.asarray(o[0], dtype=np.float64) for o in out])
+            logq = np.array([float(o[1]) for o in out])
+        lpp = self._model_lp(thp)                                                  # :82
+        u = np.empty((1, N))
+        _lib.call("rmh_rng_draw", self._rng, N, 0, 1, None, u.ctypes.data)        # the stream's uniform, :84
+        with np.errstate(divide="ignore", invalid="ignore"):
+            delta = lpp - self._lp - logq
+            mh = np.where(delta < 0.0, delta, 0.0)                                 # Python min(0, D): NaN accepts
+            ok = np.log(u[0]) < mh
+        self._th = np.where(ok[:, None], thp, self._th)
+        self._lp = np.where(ok, lpp, self._lp)
+        if not isinstance(self.proposal, DeviceProposal):
+            for row in self._th:
+                self.proposal.adapt(row)                                           # :88
+        return ok.astype(np.uint8)
+
+    def _run_mixed(self, T, nb, nt, record):
+        ths, lps, acc = [self._th.copy()], [self._lp.copy()], []
+        for _ in range(T):
+            acc.append(self._step_mixed())
+            if record:
+                ths.append(self._th.copy())
+                lps.append(self._lp.copy())
+        kept = (T - nb) // nt + 1 if T >= nb else 0
+        self._kept, self._iters = (kept if record else 0), T
+        N, d = self.Nchains, self.Npars
+        self._host_accept = np.array(acc, dtype=np.uint8).reshape(T, N)
+        if record:
+            self._host_thetas = np.array(ths)[nb::nt].reshape(kept, N, d)
+            self._host_logpost = np.array(lps)[nb::nt].reshape(kept, N)
+            if kept:   # the current state is the LAST KEPT one (sampler.py:49-50, 53-54)
+                self._th, self._lp = self._host_thetas[-1].copy(), self._host_logpost[-1].copy()
+        else:
+            self._host_thetas, self._host_logpost = np.empty((0, N, d)), np.empty((0, N))
+        if kept == 0:
+            self._th = None
 
     def __del__(self):
         for name, free in (("_hist", "rmh_history_free"), ("_state", "rmh_state_free")):
@@ -89,22 +172,41 @@ class Sampler(object):
     def _view(self, a):
         return a[:, 0] if self._single else a
 
+    # sample() and _add_state() GROW the history one state at a time (sampler.py:69-70, :89; PTSampler
+    # calls them once per sweep): earlier pieces are parked in a list and joined on the next read,
+    # so n calls cost O(n), not O(n^2) array copies.
+    def _park(self):
+        self._materialise()
+        if not hasattr(self, "_arch"):
+            self._arch = []
+        self._arch.append((self._host_thetas, self._host_logpost, self._host_accept))
+
+    def _join(self):
+        self._materialise()
+        arch = getattr(self, "_arch", None)
+        if arch:
+            arch.append((self._host_thetas, self._host_logpost, self._host_accept))
+            self._host_thetas = np.concatenate([a[0] for a in arch])
+            self._host_logpost = np.concatenate([a[1] for a in arch])
+            self._host_accept = np.concatenate([a[2] for a in arch])
+            self._arch = []
+
     @property
     def _chain_thetas(self):
         """History of states, ``(n, N, d)`` (``(n, d)`` for a single chain):
         the list of sampler.py:41,69 as one array."""
-        self._materialise()
+        self._join()
         return self._view(self._host_thetas)
 
     @property
     def _chain_logpost(self):
-        self._materialise()
+        self._join()
         return self._view(self._host_logpost)
 
     @property
     def _chain_accept(self):
         """uint8 accept flags of the iterations of the last run(), ``(T, N)``."""
-        self._materialise()
+        self._join()
         return self._view(self._host_accept)
 
     # ----------------------------------------------------------------- API --
@@ -114,9 +216,20 @@ class Sampler(object):
 
         ``record=False`` skips the history (throughput runs); the chain state
         still advances and ``current_state()`` stays valid."""
+        self._arch = []          # run() restarts the history from the current state (sampler.py:49-50)
+        return self._run(Nsamples, Nburn, Nthin, record)
+
+    def _run(self, Nsamples, Nburn=0, Nthin=1, record=True):
         T, nb, nt = int(Nsamples), int(Nburn), int(Nthin)
         if T < 0 or nb < 0 or nt < 1:
             raise _lib.ParameterError("need Nsamples >= 0, Nburn >= 0, Nthin >= 1")
+        if self._state is None:
+            if self._th is None:
+                raise IndexError("run: no current state (the previous run kept nothing)")
+            if not record and T >= nb and nb + ((T - nb) // nt) * nt != T:
+                # the state to end in is the last KEPT one: it has to be seen
+                return self._run_mixed_unrecorded(T, nb, nt)
+            return self._run_mixed(T, nb, nt, record)
         self.proposal._sync()
         self._drop_history()
         kept = (T - nb) // nt + 1 if T >= nb else 0
@@ -200,6 +313,9 @@ class Sampler(object):
         random-stream states and, for adaptive proposals, the adaptation state.
         The reference only resumes in-process (run() continues from the last state,
         sampler.py:49-50)."""
+        if self._state is None:      # mixed plugins: the chains live on the host
+            np.savez(path, theta=self._th, logpost=self._lp, rng=self._rng, single=np.bool_(self._single))
+            return
         th, lp = np.empty((self.Nchains, self.Npars)), np.empty(self.Nchains)
         _lib.call("rmh_state_get", self._state, th.ctypes.data, lp.ctypes.data)
         rng = np.empty((self.Nchains, 16), dtype=np.uint64)
@@ -222,6 +338,14 @@ class Sampler(object):
         if z["theta"].shape != (self.Nchains, self.Npars):
             raise _lib.ParameterError("checkpoint holds states of shape {}, sampler has {}"
                                       .format(z["theta"].shape, (self.Nchains, self.Npars)))
+        self._arch = []
+        if self._state is None:
+            self._th, self._lp = _lib.as_f64(z["theta"]).copy(), _lib.as_f64(z["logpost"]).copy()
+            self._rng = np.ascontiguousarray(z["rng"], dtype=np.uint64)
+            self._host_thetas, self._host_logpost = self._th[None].copy(), self._lp[None].copy()
+            self._host_accept = np.zeros((0, self.Nchains), dtype=np.uint8)
+            self._kept = 1
+            return
         _lib.call("rmh_state_set_theta", self._state, _lib.as_f64(z["theta"]))
         _lib.call("rmh_state_set_rng", self._state, np.ascontiguousarray(z["rng"], dtype=np.uint64))
         _lib.call("rmh_state_set_adapt", self._state, _lib.as_f64(z["adapt"]))
@@ -239,8 +363,18 @@ class Sampler(object):
         self._host_accept = np.zeros((0, self.Nchains), dtype=np.uint8)
         self._kept = 1
 
+    def _run_mixed_unrecorded(self, T, nb, nt):
+        self._run_mixed(T, nb, nt, True)
+        N, d = self.Nchains, self.Npars
+        self._kept = 0
+        self._host_thetas, self._host_logpost = np.empty((0, N, d)), np.empty((0, N))
+
     def current_state(self):
         """(theta, log_posterior) of the current state (sampler.py:56-60)."""
+        if self._state is None:
+            if self._th is None:
+                raise IndexError("state: no current state (empty history)")
+            return (self._th[0].copy(), float(self._lp[0])) if self._single else (self._th.copy(), self._lp.copy())
         th, lp = np.empty((self.Nchains, self.Npars)), np.empty(self.Nchains)
         _lib.call("rmh_state_get", self._state, th.ctypes.data, lp.ctypes.data)
         if self._single:
@@ -250,22 +384,24 @@ class Sampler(object):
     def _add_state(self, theta, logpost):
         """Append an explicitly given state (sampler.py:62-70; hook for
         meta-samplers).  The state becomes the chain's current state."""
-        self._materialise()
-        th = np.atleast_2d(_lib.as_f64(self.model._pack_theta(theta)))
-        _lib.call("rmh_state_set_theta", self._state, th)
+        self._park()
+        pack = getattr(self.model, "_pack_theta", None)
+        th = np.atleast_2d(_lib.as_f64(pack(theta) if pack else theta))
         lp = np.atleast_1d(np.asarray(logpost, dtype=np.float64))
-        self._host_thetas = np.concatenate([self._host_thetas, th[None]])
-        self._host_logpost = np.concatenate([self._host_logpost, lp[None]])
+        self._host_thetas, self._host_logpost = th[None].copy(), lp[None].copy()
+        self._host_accept = np.zeros((0, self.Nchains), dtype=np.uint8)
+        self._kept = 1
+        if self._state is None:
+            self._th, self._lp = th.copy(), lp.copy()
+            return
+        _lib.call("rmh_state_set_theta", self._state, th)
         self._drop_history()
 
     def sample(self):
         """One MH step appended to the history (sampler.py:72-90)."""
+        self._park()
+        self._run(1)
         self._materialise()
-        th_hist, lp_hist, acc_hist = self._host_thetas, self._host_logpost, self._host_accept
-        self.run(1)
-        self._materialise()
-        self._host_thetas = np.concatenate([th_hist, self._host_thetas[1:]])
-        self._host_logpost = np.concatenate([lp_hist, self._host_logpost[1:]])
-        self._host_accept = np.concatenate([acc_hist, self._host_accept])
+        self._host_thetas, self._host_logpost = self._host_thetas[1:], self._host_logpost[1:]
         self._drop_history()
         return self._view(self._host_thetas)[-1], self._view(self._host_logpost)[-1]

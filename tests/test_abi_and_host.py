@@ -41,8 +41,26 @@ def test_no_gpu_means_loud_failure_not_fallback():
         pytest.skip("a GPU is visible here")
     with pytest.raises(RuntimeError):
         MultiGaussianDist(np.zeros(2), np.eye(2))
-    with pytest.raises(TypeError):      # plain Python plugins are refused, not run on the CPU
+    # the abstract bases behave as the reference's (model.py:27-33, proposal.py:10-17)
+    with pytest.raises(NotImplementedError):
         riemann_amd.Sampler(riemann_amd.Model(), riemann_amd.Proposal(), np.zeros(2))
+
+    # a user's own Python plugins are the plugin API, not a CPU sampler: the chain's random
+    # stream and accept uniforms still come from the device, so without one run() fails loudly
+    class Flat(riemann_amd.Model):
+        def log_prior(self, theta):
+            return 0.0
+
+        def log_likelihood(self, theta):
+            return -0.5 * float(theta @ theta)
+
+    class Walk(riemann_amd.Proposal):
+        def propose(self, theta):
+            return theta + 0.1, 0.0
+
+    s = riemann_amd.Sampler(Flat(), Walk(), np.zeros(2))
+    with pytest.raises(RuntimeError):
+        s.run(1)
 
 
 def test_product_does_not_import_the_oracle():

@@ -1,0 +1,151 @@
+"""The mixed-plugin path (SURVEY.md 8a-8 ii, 8b "Batched extension"): the reference samples ANY
+Model / Proposal subclass (riemann/samplers/sampler.py:72-90, proposals/hamiltonian.py:60-70).
+A user's own Python Model next to a device Proposal, a Python Proposal next to a device Model,
+and VanillaHMC on a Python gradient callable run sampler.py:72-90 on the host with the chains'
+rmh-rng stream -- pinned on the reference's own runs: the numpy plugins below are the classes
+tests/golden/make_golden.py drove through the reference's Sampler to record g1 and g4."""
+import numpy as np
+import pytest
+
+from gpu_common import RTOL, check_run, load
+
+pytestmark = pytest.mark.gpu
+
+
+def _numpy_logreg(ra, X, y, tau2):
+    class LogRegModel(ra.Model):          # the plugin of make_golden.py:166-190, on this package's Model ABC
+        def log_prior(self, theta):
+            return -np.dot(theta, theta) / (2.0 * tau2)
+
+        def log_likelihood(self, theta):
+            eta = X @ theta
+            return np.sum(y * eta - np.logaddexp(0.0, eta))
+
+        def grad_log_posterior(self, theta):
+            eta = X @ theta
+            sg = np.where(eta >= 0, 1.0 / (1.0 + np.exp(-np.abs(eta))),
+                          np.exp(-np.abs(eta)) / (1.0 + np.exp(-np.abs(eta))))
+            return X.T @ (y - sg) - theta / tau2
+    return LogRegModel()
+
+
+@pytest.mark.parametrize("tag", ["mala", "hmc10"])
+def test_python_model_and_python_gradient_reproduce_the_reference_run(ra, tag):
+    """g4: numpy logistic Model + VanillaHMC(eps, L, model.grad_log_posterior), every byte of
+    arithmetic in the user's numpy code; stream, leapfrog order and accept rule are the package's."""
+    from riemann_amd.proposals import VanillaHMC
+    z = load("g4_logreg256x16_" + tag)
+    m = _numpy_logreg(ra, z["X"], z["y"], float(z["tau2"]))
+    p = VanillaHMC(float(z["eps"]), int(z["nsteps"]), m.grad_log_posterior, Npars=16)
+    s = ra.Sampler(m, p, z["theta0"], seed=int(z["seed"]))
+    s.run(32)
+    check_run(z, s)
+    th, lp = s.current_state()
+    np.testing.assert_array_equal(th, s._chain_thetas[-1])
+
+
+def test_python_model_with_device_random_walk(ra):
+    """g1: a numpy Gaussian Model sampled by the device MetropolisRandomWalk (rmh_propose on the
+    chains' stream, host log_posterior, host accept with the stream's uniform)."""
+    from riemann_amd.proposals import MetropolisRandomWalk
+    z = load("g1_gauss2d_rw")
+    Li = np.linalg.inv(np.linalg.cholesky(z["C"]))
+    logdet = np.log(np.linalg.det(z["C"]))
+
+    class Gauss(ra.Model):
+        def log_prior(self, theta):
+            return 0.0
+
+        def log_likelihood(self, theta):
+            u = Li @ (theta - z["mu"])
+            return -0.5 * (u @ u + 2 * np.log(2 * np.pi) + logdet)
+
+    s = ra.Sampler(Gauss(), MetropolisRandomWalk(z["Cprop"]), z["theta0"], seed=int(z["seed"]))
+    s.run(64)
+    check_run(z, s)
+    # thinning, resume and the one-step API on the host path
+    a = ra.Sampler(Gauss(), MetropolisRandomWalk(z["Cprop"]), z["theta0"], seed=int(z["seed"]))
+    a.run(10, 4, 3)                       # states 4, 7, 10
+    np.testing.assert_allclose(a._chain_thetas, z["thetas"][4:11:3], rtol=RTOL, atol=1e-12)
+    for t in range(11, 15):
+        th, lp = a.sample()
+        np.testing.assert_allclose(th, z["thetas"][t], rtol=RTOL, atol=1e-12)
+    assert a._chain_thetas.shape == (3 + 4, 4, 2)
+
+
+def test_device_model_with_python_proposal(ra):
+    """A user's Proposal (its own numpy generator) on a device Model: the Sampler supplies the
+    accept uniforms from the chains' stream and the device evaluates the densities."""
+    from riemann_amd import _lib
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.rng import rng_seed_host
+    Cov = np.array([[2.0, 0.6], [0.6, 1.0]])
+    m = MultiGaussianDist(np.zeros(2), Cov)
+    th0 = np.array([[0.3, -0.2], [1.0, 1.0], [-2.0, 0.5]])
+
+    class MyWalk(ra.Proposal):
+        def __init__(self, seed):
+            self.g, self.calls, self.adapted = np.random.default_rng(seed), 0, 0
+
+        def propose(self, theta):
+            self.calls += 1
+            return theta + 0.7 * self.g.standard_normal(theta.shape), 0.0
+
+        def adapt(self, theta):
+            self.adapted += 1
+
+    p = MyWalk(5)
+    s = ra.Sampler(m, p, th0, seed=21)
+    T = 25
+    s.run(T)
+    assert p.calls == 3 * T and p.adapted == 3 * T
+    # the same loop written out: sampler.py:72-90 with the stream's uniforms
+    q, rng = MyWalk(5), rng_seed_host(21, 3)
+    th, lp = th0.copy(), m.log_posterior(th0)
+    ths, acc = [th.copy()], []
+    for _ in range(T):
+        thp = np.stack([q.propose(r)[0] for r in th])
+        lpp = m.log_posterior(thp)
+        u = np.empty((1, 3))
+        _lib.call("rmh_rng_draw", rng, 3, 0, 1, None, u.ctypes.data)
+        ok = np.log(u[0]) < np.minimum(0.0, lpp - lp)
+        th, lp = np.where(ok[:, None], thp, th), np.where(ok, lpp, lp)
+        ths.append(th.copy())
+        acc.append(ok)
+    np.testing.assert_array_equal(s._chain_accept, np.array(acc, dtype=np.uint8))
+    np.testing.assert_allclose(s._chain_thetas, np.array(ths), rtol=1e-12)
+    assert 0.1 < s._chain_accept.mean() < 0.9
+
+
+def test_rng_draw_is_the_fused_kernels_stream(ra):
+    """rmh_rng_draw (normals + uniform, normals only, uniform only) against the recorded stream."""
+    from riemann_amd import _lib
+    from riemann_amd.rng import rng_seed_host
+    z = load("g1_gauss2d_rw")
+    rng = rng_seed_host(int(z["seed"]), 4)
+    xi, u = np.empty((5, 4, 2)), np.empty((5, 4))
+    _lib.call("rmh_rng_draw", rng, 4, 2, 5, xi.ctypes.data, u.ctypes.data)
+    np.testing.assert_array_equal(xi, z["xi"][:5])
+    np.testing.assert_array_equal(u, z["u"][:5])
+    x1, u1 = np.empty((1, 4, 2)), np.empty((1, 4))
+    _lib.call("rmh_rng_draw", rng, 4, 2, 1, x1.ctypes.data, None)       # normals only ...
+    _lib.call("rmh_rng_draw", rng, 4, 0, 1, None, u1.ctypes.data)       # ... then the uniform
+    np.testing.assert_array_equal(x1[0], z["xi"][5])
+    np.testing.assert_array_equal(u1[0], z["u"][5])
+
+
+def test_adaptive_device_proposals_refuse_python_models(ra):
+    from riemann_amd.proposals import AdaptScaleRandomWalk, AdaptScaleHMC
+
+    class Flat(ra.Model):
+        def log_prior(self, theta):
+            return 0.0
+
+        def log_likelihood(self, theta):
+            return -0.5 * float(theta @ theta)
+
+    s = ra.Sampler(Flat(), AdaptScaleRandomWalk(np.eye(2)), np.zeros(2), seed=1)
+    with pytest.raises(TypeError):
+        s.run(2)
+    with pytest.raises(TypeError):
+        AdaptScaleHMC(0.1, 2, lambda th: -th)

@@ -16,7 +16,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "librmh_oracle.so")
+# RMH_ORACLE_SO: another build of the same source (the sanitizer build of oracle/Makefile)
+_SO = os.environ.get("RMH_ORACLE_SO") or os.path.join(_HERE, "librmh_oracle.so")
 _lib = None
 
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -27,6 +28,8 @@ _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 def build(force=False):
     src = os.path.join(_HERE, "rmh_oracle.c")
+    if os.environ.get("RMH_ORACLE_SO"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "librmh_oracle.so"],
                               stdout=subprocess.DEVNULL)

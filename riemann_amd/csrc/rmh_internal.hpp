@@ -201,9 +201,10 @@ struct AcovUpdateArgs {
     const double *C0;    // (d, d)
     double *Cout, *Lout; // (d, d) adapted covariance (C / d^0.4) and factor (chol / d^0.2)
     double *Limg;        // lower-triangular tile image of img_scale * L, NT tiles
+    double *Ltail;       // rows 96.. of img_scale * L for k_run_rw_tail (d = 97..100), or null
     int *status;
     int d, NT;
-    double t_adapt, f4, f2, img_scale;
+    double t_adapt, f4, f2, img_scale, creg;
     int marginalize, smooth;
 };
 hipError_t launch_acov_update(const AcovUpdateArgs &a, hipStream_t st);

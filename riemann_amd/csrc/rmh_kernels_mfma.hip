@@ -227,6 +227,14 @@ hipError_t launch_moments(int NT, const double *hist, int64_t e0, int64_t e1, in
 // launch schedule of an adaptive run then needs no host round trip between updates.
 // status: set to 1 when a pivot is not positive (numpy raises LinAlgError at adaptive.py:102).
 
+// the value lane `l` (a compile-time constant) holds, as a wave-uniform scalar
+RMH_DEV double readlane_f64(double x, int l)
+{
+    const uint64_t u = (uint64_t)__double_as_longlong(x);
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)u, l), hi = __builtin_amdgcn_readlane((uint32_t)(u >> 32), l);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
 RMH_DEV double mom_at(const double *acc, int row, int col)
 {
     if (row < col) {
@@ -239,15 +247,22 @@ RMH_DEV double mom_at(const double *acc, int row, int col)
     return acc[(size_t)t * 256 + r * 64 + l];
 }
 
-__global__ void __launch_bounds__(256) k_acov_update(AcovUpdateArgs a)
+// Cholesky: blocked left-looking, panels of 16 columns, the matrix in LDS with an odd row stride.
+// Per panel (a) every element of the panel's columns receives the contributions of all columns
+// left of the panel (one thread per element, k ascending), (b) wave 0 factors the 16 x 16 diagonal
+// block (lane = row, column by column, no workgroup barrier), (c) every row below the block
+// finishes its 16 entries by forward substitution (one thread per row).  Three barriers per
+// panel, 21 at d = 100, against three per COLUMN in the unblocked version this replaces (at d = 100
+// that one lost to a host round trip: 212 vs 175 ms per 1000 iterations at the cfg2 size).  Every
+// element still receives its subtractions for k = 0, 1, 2, ... in that order, one multiply and
+// one subtract each, as the host loop (rmh_run_api.hip, cholesky_lower) does: same bits.
+__global__ void __launch_bounds__(1024) k_acov_update(AcovUpdateArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double A[]; // d x d, row-major
-    const int d = a.d, tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double A[]; // d x ds, row-major
+    const int d = a.d, ds = d | 1, tid = threadIdx.x, nth = blockDim.x;
     const double ntot = mom_at(a.acc, d, d);
-    double tr = 0.0;
-    for (int i = 0; i < d; ++i) tr += a.C0[(size_t)i * d + i];
-    const double creg = 1e-12 * (tr / d);
-    for (int idx = tid; idx < d * d; idx += 256) {
+    const double creg = a.creg;                                  // 1e-12 * mean(diag C0), adaptive.py:95-96
+    for (int idx = tid; idx < d * d; idx += nth) {
         const int i = idx / d, j = idx - i * d;
         const double cs = (mom_at(a.acc, i, j) - mom_at(a.acc, i, d) * mom_at(a.acc, j, d) / ntot) / (ntot - 1);
         double cv;
@@ -256,49 +271,104 @@ __global__ void __launch_bounds__(256) k_acov_update(AcovUpdateArgs a)
         else cv = cs + (i == j ? creg : 0.0);
         if (a.marginalize && i != j) cv = 0.0;
         cv = cv / a.f4;
-        A[idx] = cv;
+        A[i * ds + j] = cv;
         a.Cout[idx] = cv;
     }
     __syncthreads();
-    const int ti = tid >> 4, tk = tid & 15;
-    for (int j = 0; j < d; ++j) {
-        if (tid == 0) {
-            const double piv = A[j * d + j];
-            if (!(piv > 0.0)) *a.status = 1;
-            A[j * d + j] = sqrt(piv);
+    for (int p0 = 0; p0 < d; p0 += 16) {
+        const int pw = (d - p0 < 16) ? d - p0 : 16;              // columns of this panel
+        // (a) contributions of the columns left of the panel
+        if (p0 > 0) {
+            for (int e = tid; e < (d - p0) * pw; e += nth) {
+                const int i = p0 + e / pw, c = p0 + e % pw;
+                if (c <= i) {
+                    double t = A[i * ds + c];
+                    const double *ri = A + i * ds, *rc = A + c * ds;
+#pragma unroll 8
+                    for (int k = 0; k < p0; ++k) t -= ri[k] * rc[k];   // p0 is a multiple of 16
+                    A[i * ds + c] = t;
+                }
+            }
+            __syncthreads();
+        }
+        // (b) the diagonal block, wave 0: lane r holds row p0 + r of the block in registers; the
+        // pivot row's entries reach the other lanes as scalars (v_readlane), no LDS round trips
+        if (tid < 64) {
+            const int r = tid & 15;                              // (lanes 16.. shadow lanes 0..15)
+            double x[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[k] = (r < pw && k < pw) ? A[(p0 + r) * ds + p0 + k] : (r == k ? 1.0 : 0.0);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double t = x[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) t -= x[k] * readlane_f64(x[k], c); // A[r][k] * A[c][k]
+                const double piv = readlane_f64(t, c);
+                if (c < pw && !(piv > 0.0)) *a.status = 1;
+                const double ljj = sqrt(piv);
+                x[c] = (r == c) ? ljj : t / ljj;                 // rows above the diagonal: unused
+            }
+            if (tid < 16 && r < pw) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k <= r && k < pw) A[(p0 + r) * ds + p0 + k] = x[k];
+            }
         }
         __syncthreads();
-        const double ljj = A[j * d + j];
-        for (int i = j + 1 + tid; i < d; i += 256) A[i * d + j] = A[i * d + j] / ljj;
-        __syncthreads();
-        for (int i = j + 1 + ti; i < d; i += 16) {
-            const double lij = A[i * d + j];
-            for (int k = j + 1 + tk; k <= i; k += 16) A[i * d + k] = A[i * d + k] - lij * A[k * d + j];
+        // (c) the rows below the block: forward substitution against it, the row's 16 entries in
+        // registers, the block read from LDS (every lane the same address: a broadcast)
+        if (pw == 16) {
+            for (int i = p0 + 16 + tid; i < d; i += nth) {
+                double x[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) x[k] = A[i * ds + p0 + k];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    double t = x[c];
+                    const double *lc = A + (p0 + c) * ds + p0;
+#pragma unroll
+                    for (int k = 0; k < c; ++k) t -= x[k] * lc[k];
+                    x[c] = t / lc[c];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) A[i * ds + p0 + k] = x[k];
+            }
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < d * d; idx += 256) {
+    for (int idx = tid; idx < d * d; idx += nth) {
         const int i = idx / d, j = idx - i * d;
-        a.Lout[idx] = (j <= i) ? A[idx] / a.f2 : 0.0;
+        a.Lout[idx] = (j <= i) ? A[i * ds + j] / a.f2 : 0.0;
     }
     // tile image: tile (i, s), s <= 4i+3, at index 2i(i+1)+s; lane l <- L[16i + (l&15)][4s + (l>>4)]
     const int ntile = 2 * a.NT * (a.NT + 1);
-    for (int idx = tid; idx < ntile * 64; idx += 256) {
+    for (int idx = tid; idx < ntile * 64; idx += nth) {
         const int tl = idx >> 6, l = idx & 63;
         int i = 0;
         while (2 * (i + 1) * (i + 2) <= tl) ++i;
         const int sidx = tl - 2 * i * (i + 1);
         const int row = 16 * i + (l & 15), col = 4 * sidx + (l >> 4);
         double v = 0.0;
-        if (row < d && col < d && col <= row) v = A[row * d + col] / a.f2;
+        if (row < d && col < d && col <= row) v = A[row * ds + col] / a.f2;
         a.Limg[idx] = a.img_scale * v;
+    }
+    // rows 96.. for the VALU tail of k_run_rw_tail (d = 97..100), layout of pack_tail (rmh_api.hip)
+    if (a.Ltail) {
+        for (int idx = tid; idx < 7 * 64; idx += nth) a.Ltail[idx] = 0.0;
+        __syncthreads();
+        for (int idx = tid; idx < 25 * 16; idx += nth) {
+            const int sg = idx >> 4, g = (idx >> 2) & 3, r = idx & 3;
+            const int row = 96 + r, col = 4 * sg + g;
+            if (row < d && col < d && col <= row)
+                a.Ltail[((sg / 4) * 4 + g) * 16 + 4 * (sg % 4) + r] = a.img_scale * (A[row * ds + col] / a.f2);
+        }
     }
 }
 
 hipError_t launch_acov_update(const AcovUpdateArgs &a, hipStream_t st)
 {
-    const size_t lds = sizeof(double) * (size_t)a.d * a.d;
-    return launch(k_acov_update, 4, 4, lds, st, a); // one workgroup of 256 threads
+    const size_t lds = sizeof(double) * (size_t)a.d * (a.d | 1);
+    return launch(k_acov_update, 16, 16, lds, st, a); // one workgroup of 1024 threads
 }
 
 // ------------------------------------------------------------------ utilities

@@ -15,7 +15,7 @@ int comm_allreduce_sum(double *dev, size_t count);
 } // namespace rmh
 
 // ---- AdaptCovProposal, pooled over the chains (proposals/adaptive.py:38-103) -------------
-constexpr int kAcovDeviceMaxDim = 48; // covariance updates on the device up to this dimension
+constexpr int kAcovDeviceMaxDim = 111; // covariance updates on the device (the moment kernel's limit)
 constexpr int kAcovChunk = 64;   // iterations per launch at most (scratch history size)
 constexpr int kAcovWGs = 512;    // workgroups of the moment kernel: two per CU (59 KB of LDS each)
 
@@ -127,6 +127,7 @@ static int acov_update_device(rmh_proposal *p)
     a.Cout = p->d_acov_C;
     a.Lout = p->d_acov_L;
     a.Limg = p->d_Ltiles;
+    a.Ltail = has_tail(d) ? p->d_Ltail : nullptr;
     a.status = p->d_acov_status;
     a.d = d;
     a.NT = p->NT;
@@ -134,6 +135,9 @@ static int acov_update_device(rmh_proposal *p)
     a.f4 = std::pow((double)d, 0.4);
     a.f2 = std::pow((double)d, 0.2);
     a.img_scale = p->adapt_target > 0 ? 1.0 : p->scale;   // as sync_proposal packs it
+    double tr = 0.0;
+    for (int i = 0; i < d; ++i) tr += p->acov_C0[(size_t)i * d + i];
+    a.creg = 1e-12 * (tr / d);
     a.marginalize = p->acov_marg;
     a.smooth = p->acov_smooth;
     RMH_HIP(launch_acov_update(a, g_stream));
@@ -143,10 +147,9 @@ static int acov_update_device(rmh_proposal *p)
 
 static int acov_update(rmh_proposal *p)
 {
-    // Measured (tools/adaptcov_timing.py, examples): the one-workgroup device update beats the
-    // host round trip for small matrices (d = 2: 348 -> 181 ms for 10 000 steps of 4096 chains)
-    // and loses to it at d = 100 (175 -> 212 ms: ~300 barriers of a right-looking Cholesky)
-    if (p->kind == kRW && p->d <= kAcovDeviceMaxDim) return acov_update_device(p);
+    // random walk: the one-workgroup device update (blocked Cholesky in LDS, k_acov_update): no
+    // host round trip between the stretches of an adaptive run (tools/adaptcov_timing.py)
+    if (p->kind == kRW && p->d <= kAcovDeviceMaxDim && !getenv("RMH_ACOV_HOST")) return acov_update_device(p);
     const int d = p->d, D1 = d + 1, n = acov_ntri(p) * 256;
     std::vector<double> acc((size_t)n), Mm;
     if (rmh::comm_active()) {

@@ -91,6 +91,49 @@ __global__ void k_mfma_plus(double *out, int iters)
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (double)(t1 - t0) / (16.0 * iters);
 }
 
+// NM MFMAs then NV vector instructions of one kind per iteration: at two waves per SIMD, does the
+// partner's vector work hide under this wave's MFMAs?  KIND 0 v_xor_b32, 1 v_fma_f64, 2 v_mul_u32_u24,
+// 3 v_lshlrev_b64, 4 v_add_co_u32 + v_addc_co_u32 pairs, 5 v_lshlrev_b32, 6 v_and_b32, 7 v_bfe_u32, 8 v_cndmask (sgpr mask)
+template <int NM, int NV, int KIND>
+__global__ void k_mix(double *out, int iters)
+{
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    d4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    double d[8];
+    unsigned u[8];
+    unsigned long long q[8];
+    for (int i = 0; i < 8; ++i) {
+        d[i] = 1.0 + threadIdx.x * 1e-3 + i;
+        u[i] = threadIdx.x + i;
+        q[i] = threadIdx.x * 77ULL + i;
+    }
+    double b = 1.0000001, c = 1e-9;
+    long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < NM; ++k) acc[k & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, c, acc[k & 3], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (KIND == 0) asm volatile("v_xor_b32_e32 %0, %0, %1" : "+v"(u[j & 7]) : "v"(u[(j + 1) & 7]));
+            if (KIND == 1) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[j & 7]) : "v"(b), "v"(c));
+            if (KIND == 2) asm volatile("v_mul_u32_u24_e32 %0, %0, %1" : "+v"(u[j & 7]) : "v"(u[(j + 1) & 7]));
+            if (KIND == 3) asm volatile("v_lshlrev_b64 %0, 17, %0" : "+v"(q[j & 7]));
+            if (KIND == 4) asm volatile("v_add_co_u32_e32 %0, vcc, %0, %2\n\tv_addc_co_u32_e32 %1, vcc, %1, %3, vcc"
+                                        : "+v"(u[j & 7]), "+v"(u[(j + 4) & 7]) : "v"(u[(j + 1) & 7]), "v"(u[(j + 5) & 7]) : "vcc");
+            if (KIND == 5) asm volatile("v_lshlrev_b32_e32 %0, 3, %0" : "+v"(u[j & 7]));
+            if (KIND == 6) asm volatile("v_and_b32_e32 %0, %0, %1" : "+v"(u[j & 7]) : "v"(u[(j + 1) & 7]));
+            if (KIND == 7) asm volatile("v_bfe_u32 %0, %0, 3, 7" : "+v"(u[j & 7]));
+            if (KIND == 8) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(u[j & 7]) : "v"(u[(j + 1) & 7]));
+        }
+    }
+    long long t1 = clock64();
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += d[i] + u[i] + (double)q[i];
+    for (int i = 0; i < 4; ++i) s += acc[i].x;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (double)(t1 - t0);
+}
+
 template <class K>
 static void run(const char *name, K k, int threads, int iters, double *d)
 {
@@ -121,6 +164,20 @@ int main()
         R(cvt_i32_f64); R(cvt_f64_u32); R(cmp_f64); R(cndmask); R(mov_b64); R(mul_lo_u32); R(mul_u32_u24);
         R(mad_u32_u24); R(add_u32); R(xor_b32); R(alignbit); R(lshl_b64); R(lshl_add_u64);
         R(ffbh_u32); R(bfe_u32); R(lshl_add_u32); R(permlane16_swap); R(fmac_f64_dpp);
+        run("8 mfma + 64 xor", k_mix<8, 64, 0>, threads, it, d);
+        run("8 mfma + 64 fma_f64", k_mix<8, 64, 1>, threads, it, d);
+        run("8 mfma + 64 mul_u24", k_mix<8, 64, 2>, threads, it, d);
+        run("8 mfma + 64 lshl_b64", k_mix<8, 64, 3>, threads, it, d);
+        run("8 mfma + 64 add64", k_mix<8, 64, 4>, threads, it, d);
+        run("8 mfma + 64 lshl_b32", k_mix<8, 64, 5>, threads, it, d);
+        run("8 mfma + 64 and_b32", k_mix<8, 64, 6>, threads, it, d);
+        run("8 mfma + 64 bfe", k_mix<8, 64, 7>, threads, it, d);
+        run("8 mfma + 64 cndmask", k_mix<8, 64, 8>, threads, it, d);
+        run("0 mfma + 64 xor", k_mix<0, 64, 0>, threads, it, d);
+        run("0 mfma + 64 add64", k_mix<0, 64, 4>, threads, it, d);
+        run("0 mfma + 64 lshl_b32", k_mix<0, 64, 5>, threads, it, d);
+        run("0 mfma + 64 cndmask", k_mix<0, 64, 8>, threads, it, d);
+        run("8 mfma + 0", k_mix<8, 0, 0>, threads, it, d);
         run("mfma + 0 fma", k_mfma_plus<0>, threads, it, d);
         run("mfma + 4 fma_f64", k_mfma_plus<4>, threads, it, d);
         run("mfma + 8 fma_f64", k_mfma_plus<8>, threads, it, d);

@@ -195,6 +195,12 @@ int rmh_state_free(rmh_state_t s);
 /* room for `entries` kept states and `iters` accept flags per chain */
 int rmh_history_create(rmh_state_t s, int64_t entries, int64_t iters, rmh_history_t *out);
 int rmh_history_entries(rmh_history_t h, int64_t *entries, int64_t *iters);
+/* Pinned (page-locked) host memory for history downloads: rmh_history_download into such a
+ * buffer overlaps the device-side transposes with DMA transfers at the PCIe rate; into pageable
+ * memory the runtime stages every chunk.  The reference keeps its history in Python lists
+ * (samplers/sampler.py:41, 69-70); this is the hand-over of the (n, N, d) array that replaces them. */
+int rmh_host_alloc(void **ptr, uint64_t bytes);
+int rmh_host_free(void *ptr);
 /* entries [e0,e1) -> thetas (e1-e0, N, d), logpost (e1-e0, N); either may be NULL */
 int rmh_history_download(rmh_history_t h, int64_t e0, int64_t e1, double *thetas,
                          double *logpost);

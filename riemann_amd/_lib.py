@@ -70,6 +70,8 @@ SIGNATURES = {
     "rmh_state_free": [_vp],
     "rmh_history_create": [_vp, _i64, _i64, _pvp],
     "rmh_history_entries": [_vp, C.POINTER(_i64), C.POINTER(_i64)],
+    "rmh_host_alloc": [_pvp, _u64s],
+    "rmh_host_free": [_vp],
     "rmh_history_download": [_vp, _i64, _i64, _vp, _vp],
     "rmh_history_accept": [_vp, _i64, _i64, _u8],
     "rmh_history_device_ptrs": [_vp, _pvp, _pvp, _pvp, C.POINTER(_i64)],
@@ -131,3 +133,49 @@ def call(name, *args):
 
 def as_f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ---- pinned host arrays (history downloads at the PCIe rate, rmh_host_alloc) --------------------
+class PinnedPool(object):
+    """Page-locked numpy arrays for one owner (a Sampler's history downloads).  Pinning costs about
+    as much as a pageable transfer, so buffers are kept and handed out again -- but only when no
+    array created from them is referenced any more (the user may still hold the previous run's
+    history), checked through the buffer object's reference count."""
+
+    def __init__(self, max_bytes=None):
+        self.max_bytes = int(os.environ.get("RMH_PINNED_MAX_BYTES", 16 << 30)) if max_bytes is None else max_bytes
+        self._bufs = []
+
+    def _alloc(self, nbytes):
+        p = C.c_void_p()
+        call("rmh_host_alloc", C.byref(p), nbytes)
+        addr = p.value
+
+        def _free(self_buf, addr=addr):
+            try:
+                load().rmh_host_free(addr)
+            except Exception:
+                pass
+        cls = type("PinnedBuffer", (C.c_char * nbytes,), {"__del__": _free})
+        return cls.from_address(addr)
+
+    def empty(self, shape, dtype=np.float64):
+        """A pinned array of the shape, or a pageable one when the pool's budget does not allow it."""
+        import sys
+        n = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        if n == 0 or n > self.max_bytes:
+            return np.empty(shape, dtype=dtype)
+        pick = None
+        for b in self._bufs:      # free = referenced by the list, the loop variable and getrefcount only
+            if len(b) >= n and sys.getrefcount(b) <= 3 and (pick is None or len(b) < len(pick)):
+                pick = b
+        if pick is None:
+            self._bufs = [b for b in self._bufs if sys.getrefcount(b) > 3]     # drop idle smaller ones
+            if sum(len(b) for b in self._bufs) + n > self.max_bytes:
+                return np.empty(shape, dtype=dtype)
+            try:
+                pick = self._alloc(n)
+            except RuntimeError:
+                return np.empty(shape, dtype=dtype)
+            self._bufs.append(pick)
+        return np.frombuffer(pick, dtype=dtype, count=n // np.dtype(dtype).itemsize).reshape(shape)

@@ -97,6 +97,8 @@ extern bool g_init;
 extern int g_device;
 extern hipStream_t g_stream;
 extern hipEvent_t g_ev0, g_ev1;
+extern hipStream_t g_copy;
+extern hipEvent_t g_cp_ready[2], g_cp_done[2];
 extern int g_last_launches;
 extern bool g_timed;
 extern double *g_icdf; // device copy of the inverse-CDF table, 12-double cell stride

@@ -46,6 +46,7 @@ class Sampler(object):
         self.proposal = proposal
         self._seed, self._chain0 = int(seed), int(chain0)
         self._state = self._hist = None
+        self.pin_history, self._pool = True, None
         self.last_run_ms = None
         if not self._fused():
             self._init_mixed(theta0)
@@ -161,7 +162,15 @@ class Sampler(object):
         """Download the device history of the last run() on first use."""
         if self._hist is not None and self._host_thetas is None:
             n, N, d = self._kept, self.Nchains, self.Npars
-            th, lp = np.empty((n, N, d)), np.empty((n, N))
+            # histories of 64 MB and more land in pinned memory (DMA at the PCIe rate, transposes
+            # overlapped): _lib.PinnedPool; smaller ones are not worth the page-locking
+            if n * N * d * 8 >= (64 << 20) and self.pin_history:
+                if self._pool is None:
+                    self._pool = _lib.PinnedPool()
+                th = self._pool.empty((n, N, d))
+            else:
+                th = np.empty((n, N, d))
+            lp = np.empty((n, N))
             acc = np.empty((self._iters, N), dtype=np.uint8)
             if n:
                 _lib.call("rmh_history_download", self._hist, 0, n, th.ctypes.data, lp.ctypes.data)

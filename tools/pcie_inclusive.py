@@ -20,7 +20,8 @@ def main(chains=65536, its=200):
     s = ra.Sampler(ra.models.MultiGaussianDist(np.zeros(d), C), ra.proposals.MetropolisRandomWalk(2.38 ** 2 / d * C),
                    np.zeros((chains, d)), seed=1)
     s.run(its)
-    _ = s._chain_thetas          # warm-up: first download pins / pages the host buffer
+    s._chain_thetas              # warm-up: the first download page-locks its host buffer (kept by the
+    #                              Sampler's pool and reused once nothing refers to the old history)
     t0 = time.perf_counter()
     s.run(its)
     t1 = time.perf_counter()

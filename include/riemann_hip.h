@@ -204,6 +204,15 @@ int rmh_host_free(void *ptr);
 /* entries [e0,e1) -> thetas (e1-e0, N, d), logpost (e1-e0, N); either may be NULL */
 int rmh_history_download(rmh_history_t h, int64_t e0, int64_t e1, double *thetas,
                          double *logpost);
+/* Reductions of entries [e0, e1) on the device, for diagnostics at sizes where the history itself
+ * should not travel (cfg2: 53 GB of history, 105 MB of reductions): mean_dn, var_dn (d, N)
+ * parameter-major -- per chain and parameter the mean and the biased variance -- and acf
+ * (nlags, d) -- per parameter the autocorrelation function sum_t (x_t - m)(x_{t+k} - m) /
+ * sum_t (x_t - m)^2 averaged over the chains, lags 0 .. nlags-1 (nlags = 32, 64, ... 320): the
+ * input of the integrated autocorrelation time the reference's example prints
+ * (examples/test_randomwalk.py:42).  Any output may be null. */
+int rmh_history_reduce(rmh_history_t h, int64_t e0, int64_t e1, int nlags, double *mean_dn,
+                       double *var_dn, double *acf);
 /* accept flags of iterations [t0,t1) -> (t1-t0, N) uint8 */
 int rmh_history_accept(rmh_history_t h, int64_t t0, int64_t t1, uint8_t *accept);
 int rmh_history_device_ptrs(rmh_history_t h, void **thetas_edn, void **logpost_en,

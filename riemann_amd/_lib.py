@@ -73,6 +73,7 @@ SIGNATURES = {
     "rmh_host_alloc": [_pvp, _u64s],
     "rmh_host_free": [_vp],
     "rmh_history_download": [_vp, _i64, _i64, _vp, _vp],
+    "rmh_history_reduce": [_vp, _i64, _i64, _int, _vp, _vp, _vp],
     "rmh_history_accept": [_vp, _i64, _i64, _u8],
     "rmh_history_device_ptrs": [_vp, _pvp, _pvp, _pvp, C.POINTER(_i64)],
     "rmh_history_free": [_vp],

@@ -1285,6 +1285,39 @@ int rmh_history_download(rmh_history_t h, int64_t e0, int64_t e1, double *thetas
     return RMH_OK;
 }
 
+// Diagnostics of a recorded history without bringing it to the host (at the cfg2 size the history
+// is 53 GB, its reductions are 105 MB): per chain and parameter the mean and the (biased)
+// variance over entries [e0, e1), and per parameter the autocorrelation function averaged over
+// the chains, lags 0 .. nlags-1 (nlags a multiple of 32, at most 320) -- the inputs of
+// integrated_time / ESS (riemann_amd/diagnostics.py; the reference prints
+// emcee.autocorr.integrated_time of one chain, examples/test_randomwalk.py:42).
+// mean_dn, var_dn: (d, N) parameter-major; acf: (nlags, d); any of them may be null.
+int rmh_history_reduce(rmh_history_t h, int64_t e0, int64_t e1, int nlags, double *mean_dn, double *var_dn,
+                       double *acf)
+{
+    RMH_NEED_INIT();
+    if (!h || e0 < 0 || e1 > h->entries || e1 - e0 < 2) return fail(RMH_ERR_PARAM, "history_reduce: bad entry range");
+    if (nlags < 32 || nlags % 32 || nlags > 320) return fail(RMH_ERR_PARAM, "history_reduce: nlags must be 32, 64, ... 320");
+    const rmh_state *s = h->s;
+    const int64_t N = s->N, nblk = (N + 63) / 64;
+    const int d = s->d, ng = nlags / 32;
+    double *dm = nullptr, *dv = nullptr, *dp = nullptr, *da = nullptr;
+    int rc;
+    if ((rc = dev_alloc(&dm, (size_t)d * N)) || (rc = dev_alloc(&dv, (size_t)d * N)) ||
+        (rc = dev_alloc(&dp, (size_t)nblk * d * nlags)) || (rc = dev_alloc(&da, (size_t)nlags * d))) {
+        (void)hipFree(dm); (void)hipFree(dv); (void)hipFree(dp); (void)hipFree(da);
+        return rc;
+    }
+    hipError_t e = launch_hist_reduce(h->thetas, e0, e1, 4 * s->ks, s->ld, N, d, ng, dm, dv, dp, da, g_stream);
+    if (e == hipSuccess && mean_dn) e = hipMemcpyAsync(mean_dn, dm, (size_t)d * N * sizeof(double), hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess && var_dn) e = hipMemcpyAsync(var_dn, dv, (size_t)d * N * sizeof(double), hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess && acf) e = hipMemcpyAsync(acf, da, (size_t)nlags * d * sizeof(double), hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    (void)hipFree(dm); (void)hipFree(dv); (void)hipFree(dp); (void)hipFree(da);
+    RMH_HIP(e);
+    return RMH_OK;
+}
+
 int rmh_history_accept(rmh_history_t h, int64_t t0, int64_t t1, uint8_t *accept)
 {
     RMH_NEED_INIT();

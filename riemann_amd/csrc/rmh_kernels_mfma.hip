@@ -371,6 +371,103 @@ hipError_t launch_acov_update(const AcovUpdateArgs &a, hipStream_t st)
     return launch(k_acov_update, 16, 16, lds, st, a); // one workgroup of 1024 threads
 }
 
+// ---- per-chain reductions of a recorded history (rmh_history_reduce) -----------------------------
+// One wavefront = 64 chains x ONE parameter x one group of LG lags.  Pass 1: the chains' means over
+// the entries; pass 2: the centred values go through a ring of the last lag0 + LG values in LDS
+// (slot-major, lane-minor: conflict-free), and every step adds v_t v_{t-k} to the LG lag sums in
+// registers -- sum_t (x_t - m)(x_{t+k} - m), which is what the zero-padded FFT autocorrelation of
+// riemann_amd/diagnostics.py computes.  Lag group 0 also writes the chains' means and variances.
+// Per wave the 64 chains' normalised autocorrelations acov(k) / acov(0) are summed (fixed order)
+// into a partial that k_hist_acf_reduce adds up over the chain blocks: reproducible, no atomics.
+template <int LG>
+__global__ void __launch_bounds__(64) k_hist_acov(const double *hist, int64_t e0, int64_t e1, int rows, int64_t ld,
+                                                  int64_t N, int d, int ngroups, int grp, double *mean_dn,
+                                                  double *var_dn, double *partial)
+{
+    extern __shared__ __attribute__((aligned(16))) double ring[];      // (lag0 + LG) x 64
+    const int lane = threadIdx.x;
+    const int64_t nblk = (N + 63) / 64;
+    const int64_t wid = blockIdx.x;
+    const int p = (int)(wid % d);
+    const int64_t cb = wid / d;
+    const int64_t c = cb * 64 + lane;
+    const bool live = c < N;
+    const int64_t cc = live ? c : N - 1;
+    const int lag0 = grp * LG, R = lag0 + LG;
+    const int64_t n = e1 - e0, estride = (int64_t)rows * ld;
+    const double *src = hist + e0 * estride + (int64_t)p * ld + cc;
+    double m = 0.0;
+    for (int64_t t = 0; t < n; ++t) m += src[t * estride];
+    m /= (double)n;
+    double acc[LG], a0 = 0.0;
+#pragma unroll
+    for (int k = 0; k < LG; ++k) acc[k] = 0.0;
+    for (int i = lane; i < R * 64; i += 64) ring[i] = 0.0;            // zeros before the series starts
+    __builtin_amdgcn_wave_barrier();
+    int slot = 0;                                                       // slot of v_t
+    for (int64_t t = 0; t < n; ++t) {
+        const double v = src[t * estride] - m;
+        ring[slot * 64 + lane] = v;
+        a0 = fma_(v, v, a0);
+        int sk = slot - lag0;                                           // slot of v_{t - lag0}
+        sk += sk < 0 ? R : 0;
+#pragma unroll
+        for (int k = 0; k < LG; ++k) {
+            acc[k] = fma_(v, ring[sk * 64 + lane], acc[k]);
+            sk = sk == 0 ? R - 1 : sk - 1;
+        }
+        slot = slot + 1 == R ? 0 : slot + 1;
+    }
+    if (grp == 0 && live) {
+        mean_dn[(int64_t)p * N + c] = m;
+        var_dn[(int64_t)p * N + c] = a0 / (double)n;
+    }
+    // sum over the wave's chains of acov(k) / acov(0) (a constant series counts as rho = 1, as
+    // diagnostics.autocorr_1d does)
+#pragma unroll
+    for (int k = 0; k < LG; ++k) {
+        double r = live ? (a0 == 0.0 ? 1.0 : acc[k] / a0) : 0.0;
+        for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
+        if (lane == 0) partial[(cb * d + p) * (int64_t)(ngroups * LG) + lag0 + k] = r;
+    }
+}
+
+// acf[k][p] = (1/N) sum over the chain blocks, in order
+__global__ void k_hist_acf_reduce(const double *partial, int64_t nblk, int d, int K, int64_t N, double *acf)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d * K) return;
+    const int p = idx / K, k = idx % K;
+    double s = 0.0;
+    for (int64_t b = 0; b < nblk; ++b) s += partial[(b * d + p) * (int64_t)K + k];
+    acf[(int64_t)k * d + p] = s / (double)N;
+}
+
+hipError_t launch_hist_reduce(const double *hist, int64_t e0, int64_t e1, int rows, int64_t ld, int64_t N, int d,
+                              int ngroups, double *mean_dn, double *var_dn, double *partial, double *acf,
+                              hipStream_t st)
+{
+    constexpr int LG = 32;
+    const int64_t nblk = (N + 63) / 64;
+    const size_t ldsmax = sizeof(double) * (size_t)ngroups * LG * 64;
+    if (ldsmax > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_acov<LG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax);
+    if (e != hipSuccess) return e;
+    for (int grp = 0; grp < ngroups; ++grp) {   // one launch per lag group: its ring is (grp + 1) x 16 KB,
+        //                                          so the low groups run at high occupancy
+        const size_t lds = sizeof(double) * (size_t)(grp + 1) * LG * 64;
+        hipLaunchKernelGGL(k_hist_acov<LG>, dim3((unsigned)(nblk * d)), dim3(64), lds, st, hist, e0, e1, rows, ld, N,
+                           d, ngroups, grp, mean_dn, var_dn, partial);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    const int K = ngroups * LG;
+    hipLaunchKernelGGL(k_hist_acf_reduce, dim3((unsigned)((d * K + 255) / 256)), dim3(256), 0, st, partial, nblk, d, K,
+                       N, acf);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ utilities
 __global__ void k_rng_seed(uint64_t *rng, int64_t nslots, uint64_t seed, uint64_t chain0)
 {

@@ -52,6 +52,21 @@ def integrated_time(chain, c=5.0):
     return tau
 
 
+def integrated_time_from_acf(acf, c=5.0):
+    """tau_int per parameter from the chain-averaged autocorrelation functions ``acf`` (K, d), lags
+    0..K-1 (Sampler.history_stats: reduced on the device).  The estimate of a parameter whose
+    Sokal window does not close within the K lags is a lower bound; ``closed`` says which did."""
+    acf = np.asarray(acf, dtype=np.float64)
+    K, d = acf.shape
+    tau, closed = np.empty(d), np.empty(d, dtype=bool)
+    for j in range(d):
+        taus = 2.0 * np.cumsum(acf[:, j]) - 1.0
+        m = np.arange(K) < c * taus
+        closed[j] = bool(np.any(~m))
+        tau[j] = taus[int(np.argmin(m)) if closed[j] else K - 1]
+    return tau, closed
+
+
 def ess(chain, c=5.0):
     """Effective sample size per parameter, pooled over chains: N*T / tau_int."""
     x = np.asarray(chain)

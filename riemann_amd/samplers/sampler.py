@@ -263,6 +263,23 @@ class Sampler(object):
             self._host_logpost = np.empty((0, self.Nchains))
             self._host_accept = np.empty((0, self.Nchains), dtype=np.uint8)
 
+    def history_stats(self, nlags=128, c=5.0):
+        """Diagnostics of the last recorded run() reduced ON THE DEVICE (the history itself stays
+        there): ``mean``, ``var`` (N, d) per chain and parameter, ``acf`` (nlags, d) the
+        chain-averaged autocorrelation functions, ``tau`` (d,) the integrated autocorrelation
+        times (Sokal window ``c``), ``closed`` whether the window closed within ``nlags`` lags, and
+        ``ess`` = N * n / tau.  ``nlags``: 32, 64, ... 320."""
+        from .. import diagnostics as dg
+        if self._state is None or not self._hist or self._kept < 2:
+            raise IndexError("history_stats: no device history (run() with at least two kept states first)")
+        N, d, n = self.Nchains, self.Npars, self._kept
+        mean, var, acf = np.empty((d, N)), np.empty((d, N)), np.empty((nlags, d))
+        _lib.call("rmh_history_reduce", self._hist, 0, n, int(nlags), mean.ctypes.data, var.ctypes.data,
+                  acf.ctypes.data)
+        tau, closed = dg.integrated_time_from_acf(acf, c)
+        return {"mean": mean.T, "var": var.T, "acf": acf, "tau": tau, "closed": closed,
+                "ess": N * n / np.maximum(tau, 1.0)}
+
     def run_to_disk(self, prefix, Nsamples, Nburn=0, Nthin=1, chunk=1000):
         """``run(Nsamples, Nburn, Nthin)`` with the kept states streamed to disk instead of
         held in memory: ``prefix + "_thetas.npy"`` (n, N, d),

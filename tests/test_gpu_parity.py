@@ -774,3 +774,34 @@ def test_cached_gradient_is_dropped_when_another_proposal_moves_the_chain(ra, or
         np.testing.assert_array_equal(s._chain_accept, acc)
         np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
         np.testing.assert_allclose(s._chain_logpost, hl, rtol=RTOL)
+
+
+def test_history_stats_on_the_device_vs_numpy(ra):
+    """rmh_history_reduce (per-chain mean / variance, chain-averaged autocorrelation functions)
+    against numpy on the downloaded history, and the tau_int derived from it against the FFT
+    estimator of riemann_amd/diagnostics.py."""
+    from riemann_amd import diagnostics as dg
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    g = np.random.default_rng(3)
+    d, N, T = 7, 333, 1500
+    A = g.standard_normal((d, d))
+    Cov = A @ A.T + d * np.eye(d)
+    s = ra.Sampler(MultiGaussianDist(np.zeros(d), Cov), MetropolisRandomWalk(2.38 ** 2 * Cov / d),
+                   g.standard_normal((N, d)), seed=12)
+    s.run(T, 50, 1)
+    st = s.history_stats(nlags=320)
+    x = s._chain_thetas                                   # (n, N, d)
+    n = x.shape[0]
+    np.testing.assert_allclose(st["mean"], x.mean(axis=0), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(st["var"], x.var(axis=0), rtol=1e-10)
+    xc = x - x.mean(axis=0)
+    ref = np.empty((320, d))
+    a0 = np.sum(xc * xc, axis=0)
+    for k in range(320):
+        ref[k] = np.mean(np.sum(xc[: n - k] * xc[k:], axis=0) / a0, axis=0)
+    np.testing.assert_allclose(st["acf"], ref, rtol=1e-9, atol=1e-12)
+    tau = dg.integrated_time(x)
+    assert st["closed"].all()
+    np.testing.assert_allclose(st["tau"], tau, rtol=1e-8)
+    assert np.all(st["ess"] > 0)

@@ -28,7 +28,7 @@ for f in glob.glob(base + "_*/**/*counter_collection.csv", recursive=True):
 m = {}
 for k, v in vals.items():
     big = [x for x in v if x > 0.2 * max(v)]
-    m[k] = sum(big) / len(big)
+    m[k] = sum(big) / len(big) if big else 0.0
 d = {}
 if "SQ_WAVE_CYCLES" in m:
     simd_cycles = 4.0 * m["SQ_BUSY_CYCLES"] * 8    # rough: not used below
@@ -36,9 +36,14 @@ if "SQ_WAVE_CYCLES" in m:
     d["wait_inst_frac"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
     d["active_frac"] = m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"]
 if "SQ_INSTS_MFMA" in m:
-    d["valu_insts_per_mfma"] = m["SQ_INSTS_VALU"] / m["SQ_INSTS_MFMA"]
+    if m["SQ_INSTS_MFMA"] > 0:
+        d["valu_insts_per_mfma"] = m["SQ_INSTS_VALU"] / m["SQ_INSTS_MFMA"]
     d["lds_conflict_frac_of_lds_cycles"] = m["SQ_LDS_BANK_CONFLICT"] / max(1.0, m["SQ_LDS_IDX_ACTIVE"])
 d["iters_per_launch"] = iters
+if "GRBM_GUI_ACTIVE" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+    # GRBM_GUI_ACTIVE sums the 8 XCDs; MFMA busy cycles sum the 1024 SIMDs
+    d["kernel_cycles"] = m["GRBM_GUI_ACTIVE"] / 8.0
+    d["mfma_busy_frac_of_simd_cycles"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / d["kernel_cycles"]
 m["derived"] = d
 print(json.dumps(m, indent=1))
 PY

@@ -173,6 +173,22 @@ RMH_DEV double log_fast(double x)
     return r;
 }
 
+// three logarithms side by side (straight-line code: the three dependency chains interleave), one
+// rare-path test for all of them
+RMH_DEV void log_fast3(double a, double b, double c, double &la, double &lb, double &lc)
+{
+    const double tiny = 2.2250738585072014e-308, inf = __builtin_huge_val();
+    const bool oa = (a >= tiny) && (a < inf), ob = (b >= tiny) && (b < inf), oc = (c >= tiny) && (c < inf);
+    la = log_core(oa ? a : 1.0, 0);
+    lb = log_core(ob ? b : 1.0, 0);
+    lc = log_core(oc ? c : 1.0, 0);
+    if (__builtin_expect(__any(!(oa && ob && oc)), 0)) {
+        la = oa ? la : log_full(a);
+        lb = ob ? lb : log_full(b);
+        lc = oc ? lc : log_full(c);
+    }
+}
+
 // ---- link function of the logistic model (not part of the stream spec: the
 // oracle evaluates the same quantities with libm, tolerance-checked) -------------
 // Table (tools/gen_logistic_table.py): |eta| in [0, 37.5) is cut into 600 cells of width

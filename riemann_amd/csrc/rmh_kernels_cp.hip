@@ -15,6 +15,8 @@
 // per recorded sample), instruction-issue bound in practice.
 #include "rmh_run.hpp"
 
+#include <cstdlib>
+
 namespace rmh {
 
 // an opaque copy: keeps a value in a VGPR as far as the optimiser can tell
@@ -519,12 +521,237 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw_ss(CpArgs m, RwArgs pr, ChainA
     xo_store(ch.rng, ch.nslots, slot, rng);
 }
 
+// ---- the same sampler with ONE lane per chain for everything but the draws -------------------
+// k_cp_rw_ss keeps the chain in four lanes throughout, because the random stream is defined over
+// four sub-streams per chain -- but only the normals need that.  Here a wavefront owns 64 chains:
+// it draws in four passes of 16 chains (lane group g = sub-stream g, as the stream's spec wants; the
+// lane keeps the four passes' xoshiro states), parks normals and accept uniforms in an LDS row per
+// chain, and then lane l alone carries chain l through proposal, prior, the k boundary searches
+// (independent, interleaved), likelihood, accept and record.  Nothing is computed four times and
+// no lane idles through a search it has no boundary for: per chain and iteration 14 vector
+// instructions where k_cp_rw_ss issues 26 (413 per 16 chains) and k_cp_rw 69.  History rows are
+// written by 64 consecutive chains per instruction (whole 512-byte lines).
+template <int KC, int STEPS>
+__global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
+{
+    constexpr int D = 2 * KC + 2, KP = KC + 1;
+    constexpr int NT = (D + 15) / 16, S = 4 * NT, NS = (D + 3) / 4;
+    constexpr int DE = 2 * ((D + 2) / 2);        // doubles read back per chain: D normals + the uniform, even
+    constexpr int TS = 2 * ((DE / 2) | 1);       // row stride: an odd number of 16-byte units (bank spread)
+    using T = Tile<NT>;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int np = (1 << m.ss_steps) - 1;
+    double *xs = lds, *P1 = lds + np;
+    double *tab = P1 + np + 2;
+    double *xch = tab + kIcdfDoubles;            // per wave: 64 rows of TS doubles
+    for (int i = threadIdx.x; i < 2 * np + 1; i += blockDim.x) lds[i] = m.ss_xp[i];
+    icdf_stage(tab, ch.icdf);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, g = lane >> 4;
+    const int64_t grp = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;   // group of 64 chains
+    const int64_t blk0 = grp * 4;                                          // its first 16-chain block
+    if (blk0 >= ch.nblocks) return;
+    double *rows = xch + wave * (64 * TS);
+    const int64_t c = grp * 64 + lane;            // the chain this lane evaluates
+    const bool live = c < ch.ld;
+
+    double th[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) th[j] = live ? ch.theta[(int64_t)j * ch.ld + c] : 0.0;
+    double lp = live ? ch.logpost[c] : 0.0;
+    Xo st[4];                                      // pass b: chain 16 (blk0 + b) + cl, sub-stream g
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int64_t slot = ((blk0 + b < ch.nblocks) ? blk0 + b : blk0) * 64 + lane;
+        st[b] = xo_load(ch.rng, ch.nslots, slot);
+    }
+
+    int64_t knext = run.nburn, kentry = 0;
+    auto rec = [&](int64_t e) {
+        if (e != knext) return;
+        knext += run.nthin;
+        const int64_t k = kentry++;
+        if (!run.h_theta || !live) return;
+        const __amdgpu_buffer_rsrc_t r =
+            rsrc(run.h_theta + k * (int64_t)(4 * ch.ks) * ch.ld, (int64_t)(4 * ch.ks) * ch.ld);
+#pragma unroll
+        for (int j = 0; j < D; ++j) buf_store(r, (uint32_t)c * 8u, (uint32_t)ch.ld * 8u * (uint32_t)j, th[j]);
+        buf_store(rsrc(run.h_logpost + k * ch.ld, ch.ld), (uint32_t)c * 8u, 0u, lp);
+    };
+    rec(0);
+
+    const double kpc = (double)KP * (m.c_v - m.lgam_alpha);
+    for (int64_t t = 0; t < run.T; ++t) {
+        asm volatile("" ::: "memory");
+        // ---- the draws: four passes of 16 chains x 4 sub-streams.  One wave per SIMD has nobody to
+        // hide its latencies behind, so the passes are interleaved by hand: the four xoshiro steps of
+        // a word side by side, then the normals of two passes in lockstep (all table reads first,
+        // the Horner chains alternating; same operations per normal, the same bits).
+        constexpr int MW = (D + 7) / 8;
+        uint64_t w[4][MW];
+#pragma unroll
+        for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) w[b][mw] = xo_next(st[b]);
+        double ua[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) ua[b] = u01(xo_next_if(st[b], g == 0));   // the accept word: sub-stream 0
+        constexpr int PL = 1;                     // passes evaluated in lockstep
+#pragma unroll
+        for (int b0 = 0; b0 < 4; b0 += PL) {
+            uint32_t h[PL * NS];
+            double z[PL * NS];
+#pragma unroll
+            for (int q = 0; q < PL; ++q)
+#pragma unroll
+                for (int sk = 0; sk < NS; ++sk)
+                    h[q * NS + sk] = (sk & 1) ? (uint32_t)w[b0 + q][sk / 2] : (uint32_t)(w[b0 + q][sk / 2] >> 32);
+            normals_lockstep<PL * NS>(h, tab, z);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < PL; ++q) {
+                double *row = rows + (16 * (b0 + q) + cl) * TS;
+#pragma unroll
+                for (int sk = 0; sk < NS; ++sk)
+                    if (4 * sk + g < D) row[4 * sk + g] = z[q * NS + sk];
+                if (g == 0) row[D] = ua[b0 + q];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double dr[DE];
+#pragma unroll
+        for (int q = 0; q < DE / 2; ++q) {
+            const d2_t v = reinterpret_cast<const d2_t *>(rows + lane * TS)[q];
+            dr[2 * q] = v.x;
+            dr[2 * q + 1] = v.y;
+        }
+        // ---- propose: theta' = theta + scale L xi, L diagonal (randomwalk.py:26)
+        double tp[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) tp[j] = fma_(pr.Ldiag[j], dr[j], th[j]);
+        // ---- prior (changepoint.py:128-160, alpha = 1: see k_cp_rw_ss)
+        double prod = 1.0, dmin = __builtin_huge_val(), vsum = 0.0, vmin = __builtin_huge_val();
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const double lo = (j == 0) ? m.xmin : tp[j - 1 < 0 ? 0 : j - 1];
+            const double hi = (j == KC) ? m.xmax : tp[j < KC ? j : 0];
+            const double dx = hi - lo;
+            prod *= dx;
+            dmin = __builtin_fmin(dmin, dx);
+            vsum += tp[KC + j];
+            vmin = __builtin_fmin(vmin, tp[KC + j]);
+        }
+        const double nan = __builtin_nan("");
+        const double sig = tp[D - 1], sig2 = sig * sig;
+        // the iteration's three logarithms side by side: log(sig^2), log(prod ds) and log(u) of the
+        // accept test (sampler.py:84; log_core is that test's logarithm, log(0) = -inf)
+        double lsig2, lprod, lu;
+        log_fast3(sig2, prod, dr[D], lsig2, lprod, lu);
+        const double ps = (dmin > 0.0) ? lprod : (dmin == 0.0 ? -__builtin_huge_val() : nan);
+        const double pv = (vmin > 0.0) ? fma_(-m.beta, vsum, kpc) : nan;
+        const double p2 = (sig < 0.0) ? nan : -lsig2;
+        double logP = ((m.c_k + pv) + ((m.c_s + ps) - m.c_sL)) + p2;
+        if (logP != logP) logP = -__builtin_huge_val();
+        double lpp = -__builtin_huge_val();
+        if (__any(logP > -__builtin_huge_val())) {
+            // ---- likelihood: the KC boundary searches of this chain, step by step side by side
+            int lo8[KC];
+#pragma unroll
+            for (int j = 0; j < KC; ++j) lo8[j] = 0;
+            if (STEPS > 0) {
+#pragma unroll
+                for (int sp = STEPS - 1; sp >= 0; --sp)
+#pragma unroll
+                    for (int j = 0; j < KC; ++j) {
+                        const double xv = *reinterpret_cast<const double *>(
+                            reinterpret_cast<const char *>(xs) + lo8[j] + ((8 << sp) - 8));
+                        lo8[j] += (xv <= tp[j]) ? (8 << sp) : 0;
+                    }
+            } else {
+                for (int sp = m.ss_steps - 1; sp >= 0; --sp) {
+                    const int step8 = 8 << sp;
+#pragma unroll
+                    for (int j = 0; j < KC; ++j) {
+                        const double xv = *reinterpret_cast<const double *>(
+                            reinterpret_cast<const char *>(xs) + lo8[j] + step8 - 8);
+                        lo8[j] += (xv <= tp[j]) ? step8 : 0;
+                    }
+                }
+            }
+            double acc = 0.0, bprev = 0.0, pprev = 0.0;
+#pragma unroll
+            for (int pz = 0; pz < KP; ++pz) {
+                const int b8 = pz < KC ? lo8[pz < KC ? pz : 0] : 8 * m.n;
+                const double bcur = (double)(b8 >> 3);
+                const double pcur = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(P1) + b8);
+                const double vc = tp[KC + pz] - m.ss_ym;
+                acc = fma_(vc, fma_(bcur - bprev, vc, -2.0 * (pcur - pprev)), acc);
+                bprev = bcur;
+                pprev = pcur;
+            }
+            const double ss = (m.ss_p2 + acc) / sig2;
+            double logL = -0.5 * ((ss + m.n * lsig2) + m.nlog2pi);
+            if (logL != logL) logL = -__builtin_huge_val();
+            lpp = combine_post(logP, logL);
+        }
+        // ---- accept (sampler.py:83-84)
+        const double delta = lpp - lp - 0.0;
+        const bool ok = lu < ((delta < 0.0) ? delta : 0.0);
+#pragma unroll
+        for (int j = 0; j < D; ++j) th[j] = ok ? tp[j] : th[j];
+        lp = ok ? lpp : lp;
+        if (run.h_accept && live) run.h_accept[t * ch.ld + c] = ok ? 1 : 0;
+        rec(t + 1);
+    }
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) ch.theta[(int64_t)j * ch.ld + c] = th[j];
+        ch.logpost[c] = lp;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        if (blk0 + b < ch.nblocks) xo_store(ch.rng, ch.nslots, (blk0 + b) * 64 + lane, st[b]);
+}
+
 template <int KC>
 static hipError_t cp_rw_ss_launch(const CpArgs &m, const RwArgs &p, const ChainArgs &c,
                                   const RunArgs &r, hipStream_t st)
 {
-    constexpr int D = 2 * KC + 2, TS = 2 * (((D + 1) / 2) | 1), BS = 2 * (KC | 1);
-    const int nw = 8, np = (1 << m.ss_steps) - 1;
+    constexpr int D = 2 * KC + 2;
+    const int np = (1 << m.ss_steps) - 1;
+    // one lane per chain (k_cp_rw_ss64: 4 waves x 64 chains per workgroup) once there are enough
+    // chains to give every SIMD of the chip a wavefront of 64 (65 536: one each); below that the
+    // four-lanes-per-chain kernel keeps four times as many waves in flight
+    if (getenv("RMH_CP_SS64") || (c.nblocks >= 4096 && !getenv("RMH_CP_SS16"))) {
+        constexpr int DE = 2 * ((D + 2) / 2), TS64 = 2 * ((DE / 2) | 1);
+        const int nw = 4;
+        const size_t lds = sizeof(double) * ((size_t)2 * np + 2 + kIcdfDoubles + (size_t)nw * 64 * TS64);
+        if (lds <= 160 * 1024) {
+            const int64_t ngrp = (c.nblocks + 3) / 4;
+            const dim3 grid((unsigned)((ngrp + nw - 1) / nw));
+#define RMH_CP_SS64(STEPS)                                                                            \
+    {                                                                                                 \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cp_rw_ss64<KC, STEPS>),   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        if (e != hipSuccess) return e;                                                                \
+        hipLaunchKernelGGL((k_cp_rw_ss64<KC, STEPS>), grid, dim3(64 * nw), lds, st, m, p, c, r);      \
+        return hipGetLastError();                                                                     \
+    }
+            switch (m.ss_steps) {
+            case 6: RMH_CP_SS64(6)
+            case 7: RMH_CP_SS64(7)
+            case 8: RMH_CP_SS64(8)
+            default: RMH_CP_SS64(0)
+            }
+#undef RMH_CP_SS64
+        }
+    }
+    constexpr int TS = 2 * (((D + 1) / 2) | 1), BS = 2 * (KC | 1);
+    const int nw = 8;
     const size_t lds = sizeof(double) * ((size_t)2 * np + 2 + kIcdfDoubles + (size_t)nw * 16 * (TS + BS));
     if (lds > 80 * 1024) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((c.nblocks + nw - 1) / nw));

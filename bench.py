@@ -324,12 +324,12 @@ def measure(name, a, ranks, steps, warmup, iters=0, with_cpu=True, with_ess=True
                      "flops_per_chain_iteration": w["flops"],
                      "bytes_per_chain_iteration": w["bytes"]},
     }
-    if name == "changepoint_rw" and prof.get("valu_insts_per_wave_iteration"):
-        # the kernel's real bound: VALU issue (one instruction per 4 cycles per SIMD, 16 chains per
-        # wave) at the committed instruction count (profiles/r02_sq_counters.json)
-        vi = prof["valu_insts_per_wave_iteration"]
-        roof = 256 * 4 * 2.4e9 / 4.0 / vi * 16
-        out["roofline"]["valu_issue"] = {"insts_per_wave_iteration": vi, "roof_chain_iterations_per_s": roof,
+    if name == "changepoint_rw" and prof.get("valu_insts_per_chain_iteration"):
+        # the kernel's real bound: vector-instruction issue, one per 4 cycles per SIMD on 1024 SIMDs at
+        # 2.4 GHz, at the committed instruction count per chain-iteration (profiles/r02_sq_counters.json)
+        vi = prof["valu_insts_per_chain_iteration"]
+        roof = 1024 * 2.4e9 / 4.0 / vi
+        out["roofline"]["valu_issue"] = {"insts_per_chain_iteration": vi, "roof_chain_iterations_per_s": roof,
                                          "frac": (N * iters / (kms * 1e-3)) / roof}
     if pooled:
         out["pool"] = pooled

@@ -28,8 +28,8 @@ def last_json_line(path):
 
 for w in ("logreg_mala", "logreg_hmc", "gauss_rw", "changepoint_rw", "pt_gauss"):
     st = glob.glob(os.path.join(G, "prof", w, "**", "*kernel_stats.csv"), recursive=True)
-    if st:
-        shutil.copy(st[0], os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, w)))
+    if st:   # gpurun_out/ accumulates over sessions: the newest run is the one that belongs to this round
+        shutil.copy(max(st, key=os.path.getmtime), os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, w)))
     for src, dst in (("%s_bench.json" % w, "%s_%s_bench.json"), ("%s_under.json" % w, "%s_%s_bench_under_rocprof.json")):
         f = os.path.join(G, "prof", src)
         if os.path.exists(f) and last_json_line(f):
@@ -63,9 +63,9 @@ for w, it in ITERS.items():
               "write_GB": round(wr / 1e9, 4),
               "hbm_bytes_per_chain_iteration": round((2 * fe + wr) / (65536 * it), 1),
               "algorithmic_bytes_per_chain_iteration": ALGO[w]})
-    if w in sq and "SQ_INSTS_VALU" in sq[w]:
-        waves = 65536 / 16
-        e["valu_insts_per_wave_iteration"] = round(sq[w]["SQ_INSTS_VALU"] / (waves * it), 1)
+    if w in sq and "SQ_INSTS_VALU" in sq[w]:   # (a wavefront holds 16 chains, or 64 in k_cp_rw_ss64)
+        e.pop("valu_insts_per_wave_iteration", None)
+        e["valu_insts_per_chain_iteration"] = round(sq[w]["SQ_INSTS_VALU"] / (65536.0 * it), 2)
     pmc[w] = e
 json.dump(pmc, open(pmc_path, "w"), indent=1)
 print("profiles/ updated for", tag)

@@ -1237,14 +1237,25 @@ int rmh_history_download(rmh_history_t h, int64_t e0, int64_t e1, double *thetas
         int64_t chunk = (256LL << 20) / (per * 8);
         if (chunk < 1) chunk = 1;
         if (chunk > e1 - e0) chunk = e1 - e0;
-        double *nd[2] = {nullptr, nullptr};
-        int rc = dev_alloc(&nd[0], (size_t)chunk * per);
-        if (!rc && e1 - e0 > chunk) rc = dev_alloc(&nd[1], (size_t)chunk * per);
-        if (rc) {
-            (void)hipFree(nd[0]);
-            return rc;
+        // the two staging buffers are kept by the library (hipMalloc / hipFree of 2 x 256 MiB per
+        // call cost as much as moving several GB)
+        static double *stage[2] = {nullptr, nullptr};
+        static size_t stage_n = 0;
+        if (stage_n < (size_t)chunk * per) {
+            (void)hipFree(stage[0]);
+            (void)hipFree(stage[1]);
+            stage[0] = stage[1] = nullptr;
+            stage_n = 0;
+            int rc = dev_alloc(&stage[0], (size_t)chunk * per);
+            if (!rc) rc = dev_alloc(&stage[1], (size_t)chunk * per);
+            if (rc) {
+                (void)hipFree(stage[0]);
+                stage[0] = nullptr;
+                return rc;
+            }
+            stage_n = (size_t)chunk * per;
         }
-        if (!nd[1]) nd[1] = nd[0];
+        double *nd[2] = {stage[0], stage[1]};
         hipError_t e = hipSuccess;
         int k = 0;
         for (int64_t a = e0; a < e1 && e == hipSuccess; a += chunk, ++k) {
@@ -1270,8 +1281,6 @@ int rmh_history_download(rmh_history_t h, int64_t e0, int64_t e1, double *thetas
         }
         hipError_t e2 = hipStreamSynchronize(g_copy);
         hipError_t e3 = hipStreamSynchronize(g_stream);
-        if (nd[1] != nd[0]) (void)hipFree(nd[1]);
-        (void)hipFree(nd[0]);
         RMH_HIP(e);
         RMH_HIP(e2);
         RMH_HIP(e3);

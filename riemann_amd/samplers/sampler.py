@@ -240,12 +240,18 @@ class Sampler(object):
                 return self._run_mixed_unrecorded(T, nb, nt)
             return self._run_mixed(T, nb, nt, record)
         self.proposal._sync()
-        self._drop_history()
         kept = (T - nb) // nt + 1 if T >= nb else 0
         hist = None
+        # a device history of the same shape is written again rather than freed and re-allocated
+        # (chunked runs, run_to_disk: freeing / mapping 10 GB per call halves the download rate that
+        # follows, tools/dl_probe*.py)
+        if not (record and self._hist and getattr(self, "_hist_shape", None) == (kept, T)):
+            self._drop_history()
         if record:
-            self._hist = C.c_void_p()
-            _lib.call("rmh_history_create", self._state, kept, T, C.byref(self._hist))
+            if not self._hist:
+                self._hist = C.c_void_p()
+                _lib.call("rmh_history_create", self._state, kept, T, C.byref(self._hist))
+                self._hist_shape = (kept, T)
             hist = self._hist
         _lib.call("rmh_run", self.model._h, self.proposal._h, self._state, T, nb, nt, hist)
         _lib.call("rmh_synchronize")

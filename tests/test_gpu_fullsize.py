@@ -119,3 +119,32 @@ def test_cfg5_changepoint_16384_chains_vs_oracle(ra, orc):
     fin = np.isfinite(hl)
     assert np.array_equal(np.isfinite(s._chain_logpost), fin)
     np.testing.assert_allclose(s._chain_logpost[fin], hl[fin], rtol=RTOL)
+
+
+def test_cfg5_three_kernels_agree_at_full_size(ra):
+    """cfg5 at 65 536 chains through the three kernels that can run it -- k_cp_rw (O(n) likelihood,
+    round 1), k_cp_rw_ss (sufficient statistics, four lanes per chain) and k_cp_rw_ss64 (one lane
+    per chain): same stream, same accept decisions, states equal to rounding."""
+    import os
+    from riemann_amd.models import ChangepointRegression1D
+    from riemann_amd.proposals import MetropolisRandomWalk
+    from riemann_amd.workloads import changepoint_data
+    x, y, truth, cdiag = changepoint_data()
+    th0 = truth + 0.01 * np.random.default_rng(5).standard_normal((N, 12))
+    th0[:, :5] = np.sort(th0[:, :5], axis=1)
+    out = {}
+    for name, env in (("ss64", {}), ("ss16", {"RMH_CP_SS16": "1"}), ("on", {"RMH_CP_NO_SS": "1"})):
+        os.environ.update(env)
+        try:
+            p = MetropolisRandomWalk(np.diag(cdiag))
+            p.scale = 0.1
+            s = ra.Sampler(ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=5), p, th0, seed=8)
+            s.run(150, 0, 50)
+            out[name] = (s._chain_accept.copy(), s._chain_thetas.copy(), s._chain_logpost.copy())
+        finally:
+            for k in env:
+                del os.environ[k]
+    for name in ("ss16", "on"):
+        np.testing.assert_array_equal(out["ss64"][0], out[name][0])
+        np.testing.assert_allclose(out["ss64"][1], out[name][1], rtol=RTOL, atol=1e-12)
+        np.testing.assert_allclose(out["ss64"][2], out[name][2], rtol=RTOL)

@@ -130,14 +130,14 @@ def test_pooled_covariance_adaptation_finds_the_target_covariance(target):
     moments_ok(s.current_state()[0], mu, Ct)
 
 
-@pytest.mark.parametrize("kind", ["rw", "adapt_rw", "pt"])
+@pytest.mark.parametrize("kind", ["rw", "adapt_rw", "pt", "pcn", "mala", "hmc", "hmc_mass"])
 def test_cfg2_size_target_is_invariant(kind):
     """The same property at the headline shape (d = 100, 65 536 chains): the kernels that run
     there (four tail rows on the VALU through DPP row broadcasts, row-swap reductions, the
     fixed-length stream) differ from the generic ones the d = 20 cases above exercise."""
     import riemann_amd as ra
     from riemann_amd.models import MultiGaussianDist
-    from riemann_amd.proposals import AdaptScaleRandomWalk, MetropolisRandomWalk
+    from riemann_amd.proposals import MALA, AdaptScaleRandomWalk, MetropolisRandomWalk, VanillaHMC, pCN
     from riemann_amd.samplers import PTSampler
     d = 100
     g = np.random.default_rng(2024)
@@ -162,10 +162,13 @@ def test_cfg2_size_target_is_invariant(kind):
             th, _ = pt.samplers[i].current_state()
             moments_ok(th, mu, Ct / b)
         return
-    p = MetropolisRandomWalk(Cp) if kind == "rw" else AdaptScaleRandomWalk(Cp)
+    p = {"rw": lambda: MetropolisRandomWalk(Cp), "adapt_rw": lambda: AdaptScaleRandomWalk(Cp),
+         "pcn": lambda: pCN(0.5 * np.eye(d), 0.95), "mala": lambda: MALA(0.35, m),
+         "hmc": lambda: VanillaHMC(0.25, 5, m),
+         "hmc_mass": lambda: VanillaHMC(0.3, 3, m, M=np.linalg.inv(Ct))}[kind]()
     th0 = mu + g.standard_normal((N, d)) @ Lt.T
     s = ra.Sampler(m, p, th0, seed=13)
-    s.run(60, record=False)
+    s.run(60 if kind in ("rw", "adapt_rw", "pcn") else 25, record=False)
     th, lp = s.current_state()
     moments_ok(th, mu, Ct)
     np.testing.assert_allclose(lp, m.log_posterior(th), rtol=1e-9)

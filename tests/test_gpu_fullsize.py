@@ -148,3 +148,33 @@ def test_cfg5_three_kernels_agree_at_full_size(ra):
         np.testing.assert_array_equal(out["ss64"][0], out[name][0])
         np.testing.assert_allclose(out["ss64"][1], out[name][1], rtol=RTOL, atol=1e-12)
         np.testing.assert_allclose(out["ss64"][2], out[name][2], rtol=RTOL)
+
+
+@pytest.mark.parametrize("n", [1000, 17, 64 * 9 + 16])
+def test_cfg5_one_lane_per_chain_kernel_ragged_chain_counts(ra, orc, n):
+    """k_cp_rw_ss64 owns 64 chains per wavefront: chain counts that leave its last wavefront one,
+    two or three 16-chain blocks short (forced here; by itself it takes over at 65 536 chains)."""
+    import os
+    from riemann_amd.models import ChangepointRegression1D
+    from riemann_amd.proposals import MetropolisRandomWalk
+    from riemann_amd.workloads import changepoint_data
+    x, y, truth, cdiag = changepoint_data()
+    th0 = truth + 0.01 * np.random.default_rng(n).standard_normal((n, 12))
+    th0[:, :5] = np.sort(th0[:, :5], axis=1)
+    p = MetropolisRandomWalk(np.diag(cdiag))
+    p.scale = 0.1
+    os.environ["RMH_CP_SS64"] = "1"
+    try:
+        s = ra.Sampler(ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=5), p, th0, seed=6, chain0=5)
+        s.run(60, 7, 2)
+        s.run(41)
+    finally:
+        del os.environ["RMH_CP_SS64"]
+    om = orc.Changepoint(x, y, 5, 1.0, 3.0, 5.0, 1.0, 1.0)
+    th, st = th0.copy(), orc.rng_seed(6, n, chain0=5)
+    lp = om.log_posterior(th)
+    ht, hl, _ = orc.run(om, orc.RandomWalk(np.diag(cdiag), 0.1), th, lp, st, 60)
+    th, lp = ht[7::2][-1].copy(), hl[7::2][-1].copy()           # the last KEPT state (59)
+    ht, hl, acc = orc.run(om, orc.RandomWalk(np.diag(cdiag), 0.1), th, lp, st, 41)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)

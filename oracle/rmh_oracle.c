@@ -1004,7 +1004,7 @@ int orc_run_pt(const orc_model *m, const orc_proposal *p, int64_t S, double *the
                double *hist_theta, double *hist_logpost, uint8_t *code)
 {
     const int d = m->d;
-    if (p->d != d || (p->kind != ORC_RW && p->kind != ORC_HMC) || K < 1 || K > 16 || (S & 15)) return -1;
+    if (p->d != d || (p->kind != ORC_RW && p->kind != ORC_HMC && p->kind != ORC_PCN) || K < 1 || K > 16 || (S & 15)) return -1;
     const int EPW = 16 / K;
     double *work = (double *)malloc(sizeof(double) * d * 8);
     double *xi = work, *thp = work + d, *w2 = work + 2 * d;

@@ -1177,7 +1177,7 @@ hipError_t launch_cp_rw_ss(int k, const CpArgs &m, const RwArgs &p, const ChainA
 }
 
 // the generic fused kernels over the changepoint policy: variant 1 = AdaptScale random walk,
-// 2 = pCN, 3 = AdaptScalepCN, 4 = parallel tempering, 0 = plain (used by the covariance adaptation)
+// 2 = pCN, 3 = AdaptScalepCN, 4 = parallel tempering, 5 = pCN within parallel tempering, 0 = plain (used by the covariance adaptation)
 template <int KC>
 static hipError_t cp_generic_launch(const CpArgs &m, const RwArgs &p, const ChainArgs &c,
                                     const RunArgs &r, int variant, hipStream_t st)
@@ -1198,6 +1198,7 @@ static hipError_t cp_generic_launch(const CpArgs &m, const RwArgs &p, const Chai
     case 2: RMH_CP_GEN(false, true, false); break;
     case 3: RMH_CP_GEN(true, true, false); break;
     case 4: RMH_CP_GEN(false, false, true); break;
+    case 5: RMH_CP_GEN(false, true, true); break;
     default: return hipErrorInvalidValue;
     }
 #undef RMH_CP_GEN

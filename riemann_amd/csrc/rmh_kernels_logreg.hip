@@ -45,6 +45,7 @@ hipError_t launch_logreg_pcn(int NT, const LogRegArgs &m, const RwArgs &p, const
     RMH_NT_DISPATCH(NT, {
         using M = LogRegModel<kNT>;
         const size_t lds = sizeof(double) * (M::lds_doubles(false) + kIcdfDoubles);
+        if (r.pt_K > 0) return launch(k_run_rw<M, 4, false, true, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
         if (adapt) return launch(k_run_rw<M, 4, true, true, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
         return launch(k_run_rw<M, 4, false, true, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
     })
@@ -68,8 +69,10 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
                 return launch(k_run_hmc<MT, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);
             }
         }
-        if (r.pt_K > 0) // parallel tempering: plain HMC / MALA within the rungs
+        if (r.pt_K > 0) { // parallel tempering: HMC / MALA (with or without a mass matrix) within the rungs
+            if (p.chM) return launch(k_run_hmc<M, 4, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
             return launch(k_run_hmc<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
+        }
         if (p.chM) { // mass-matrix variant: one wave per SIMD (register budget)
             if (adapt) return launch(k_run_hmc<M, 4, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
             return launch(k_run_hmc<M, 4, false, true>, c.nblocks, 4, lds, st, m, p, c, r);

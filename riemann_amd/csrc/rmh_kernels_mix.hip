@@ -63,6 +63,7 @@ hipError_t launch_mix_pcn(int NT, const MixArgs &m, const RwArgs &p, const Chain
     RMH_NT_DISPATCH(NT, {
         using M = MixModel<kNT>;
         const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + kIcdfDoubles);
+        if (r.pt_K > 0) return launch(k_run_rw<M, 4, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
         if (adapt) return launch(k_run_rw<M, 4, true, true, false>, c.nblocks, 4, lds, st, m, p, c, r);
         return launch(k_run_rw<M, 4, false, true, false>, c.nblocks, 4, lds, st, m, p, c, r);
     })

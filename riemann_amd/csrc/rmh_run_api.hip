@@ -346,9 +346,11 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         r.h_logpost = sink.logpost;
     }
     if (K > 0) { // parallel tempering: the slots' inverse temperatures
-        if ((p->kind != kRW && p->kind != kHMC) || adapt || p->acov || p->nblk > 0 || (p->kind == kHMC && p->d_chM))
-            return fail(RMH_ERR_PARAM, "run_pt: built for MetropolisRandomWalk and VanillaHMC / MALA (no mass matrix, "
-                                       "no adaptation) within-chain moves");
+        // adaptive proposals: the reference hands ONE proposal object to every rung (ptsampler.py:82), so
+        // its adaptation state would couple the rungs of a sweep sequentially -- not built
+        if ((p->kind != kRW && p->kind != kHMC && p->kind != kPCN) || adapt || p->acov || p->nblk > 0)
+            return fail(RMH_ERR_PARAM, "run_pt: built for MetropolisRandomWalk, pCN and VanillaHMC / MALA "
+                                       "within-chain moves (no adaptation)");
         if (p->kind == kHMC && m->kind != kGauss && m->kind != kLogReg)
             return fail(RMH_ERR_PARAM, "run_pt: this model has no gradient");
         std::vector<double> b((size_t)s->ld, 1.0);
@@ -387,9 +389,15 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         launches = 0;
         if ((rc = run_adaptcov(m, p, s, c, T, r.nburn, r.nthin, need_last ? &sink : h, &launches))) return rc;
     } else if (K > 0 && p->kind == kHMC) {
-        HmcArgs ha{p->eps, p->nsteps, nullptr, nullptr, nullptr, 1.0};
+        HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT, p->minv};
         e = m->kind == kGauss ? launch_gauss_hmc(m->NT, m->ga, ha, c, r, false, g_stream)
                               : launch_logreg_hmc(m->NT, m->la, ha, c, r, false, g_stream);
+    } else if (K > 0 && p->kind == kPCN) {
+        RwArgs ra{p->d_Ltiles, p->d_V, p->rho};
+        e = m->kind == kGauss         ? launch_gauss_pcn(m->NT, m->ga, ra, c, r, false, g_stream)
+            : m->kind == kLogReg      ? launch_logreg_pcn(m->NT, m->la, ra, c, r, false, g_stream)
+            : m->kind == kChangepoint ? launch_cp_generic(m->k, m->ca, ra, c, r, 5, g_stream)
+                                      : launch_mix_pcn(m->NT, m->ma, ra, c, r, false, g_stream);
     } else if (K > 0) {
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
         const bool tail = m->kind == kGauss && m->ga.Wtail && p->d_Ltail && !getenv("RMH_NO_TAIL");

@@ -85,7 +85,8 @@ class PTSampler(object):
     def __init__(self, model, proposal, theta0, betas=None, Pswap=0.1, seed=0, chain0=0):
         """
         :param model: device Model to sample (MultiGaussianDist or MixtureDist)
-        :param proposal: MetropolisRandomWalk used within every rung
+        :param proposal: the proposal used within every rung (MetropolisRandomWalk, pCN,
+            VanillaHMC / MALA with or without a mass matrix; adaptive proposals are refused)
         :param theta0: initial parameters, ``(d,)`` or ``(Ne, d)``; every rung of an
             ensemble starts there (ptsampler.py:82)
         :param betas: temperature ladder, default ``0.5**arange(5)`` (:60)

@@ -3,7 +3,7 @@ comparisons, random-walk and HMC within-chain moves."""
 import numpy as np
 import pytest
 
-from gpu_common import RTOL, check_pt, load  # noqa: F401
+from gpu_common import MIX2D, RTOL, check_pt, load  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -136,3 +136,63 @@ def test_parallel_tempering_with_hmc_within_the_rungs(ra, orc):
         np.testing.assert_allclose(pt._host_thetas, ht[:, idx], rtol=1e-8, atol=1e-10)
         np.testing.assert_allclose(pt._host_logpost, hl[:, idx], rtol=1e-8)
         assert (code[:, idx] == 3).sum() > 20 and (code[:, idx] == 1).sum() > 100
+
+
+def test_parallel_tempering_with_pcn_and_mass_matrix_hmc_within_the_rungs(ra, orc):
+    """The other stateless proposals of the reference inside PTSampler: pCN (asymmetric logqratio,
+    randomwalk.py:78-101) on the Gaussian, mixture, logistic and changepoint models, and
+    VanillaHMC / MALA with a mass matrix (hamiltonian.py:71-87) on the Gaussian and logistic
+    models; many ladders against the oracle.  Adaptive proposals stay refused: the reference
+    hands one proposal object to all rungs (ptsampler.py:82)."""
+    from riemann_amd.models import ChangepointRegression1D, LogisticRegression, MultiGaussianDist, benchmarks as b
+    from riemann_amd.proposals import AdaptScaleRandomWalk, VanillaHMC, pCN
+    from riemann_amd.samplers import PTSampler
+    from riemann_amd.workloads import changepoint_data, logreg_data
+    g = np.random.default_rng(21)
+    d = 100
+    A = g.standard_normal((d, d))
+    Cm = A @ A.T / d + 0.5 * np.eye(d)
+    X, y = logreg_data(300, 24, seed=5)
+    x, yy, truth, cdiag = changepoint_data()
+    mix = b.benchmark_gauss2d_mix2_cross
+    omix = orc.Mixture(MIX2D)
+    Mm = np.diag(g.uniform(0.5, 2.0, 24)) + 0.1 * np.ones((24, 24))
+    Mg = np.linalg.inv(Cm)
+    cases = [
+        ("pcn gauss", MultiGaussianDist(np.zeros(d), Cm), orc.Gaussian(np.zeros(d), Cm), d,
+         lambda m: pCN(Cm, 0.9), lambda: orc.PCN(Cm, 0.9), 5, 0.3 * g.standard_normal((150, d))),
+        ("pcn logreg", LogisticRegression(X, y, 100.0), orc.LogReg(X, y, 100.0), 24,
+         lambda m: pCN(0.01 * np.eye(24), 0.95), lambda: orc.PCN(0.01 * np.eye(24), 0.95), 4, 0.3 * g.standard_normal((150, 24))),
+        ("pcn changepoint", ChangepointRegression1D(x, yy, 1.0, 3.0, 5.0, 10, 1, 1, k=5),
+         orc.Changepoint(x, yy, 5, 1.0, 3.0, 5.0, 1.0, 1.0), 12,
+         lambda m: pCN(np.diag(0.01 * cdiag), 0.999), lambda: orc.PCN(np.diag(0.01 * cdiag), 0.999), 3,
+         None),
+        ("hmc mass gauss", MultiGaussianDist(np.zeros(d), Cm), orc.Gaussian(np.zeros(d), Cm), d,
+         lambda m: VanillaHMC(0.3, 3, m, M=Mg), lambda: orc.HMC(0.3, 3, d, M=Mg), 5, 0.3 * g.standard_normal((150, d))),
+        ("mala mass logreg", LogisticRegression(X, y, 100.0), orc.LogReg(X, y, 100.0), 24,
+         lambda m: VanillaHMC(0.3, 1, m, M=Mm), lambda: orc.HMC(0.3, 1, 24, M=Mm), 4, 0.3 * g.standard_normal((150, 24))),
+    ]
+    if omix is not None:
+        cases.append(("pcn mixture", mix, omix, 2, lambda m: pCN(1.5 * np.eye(2), 0.8), lambda: orc.PCN(1.5 * np.eye(2), 0.8),
+                      5, g.standard_normal((150, 2))))
+    for name, m, om, dd, mkp, mko, K, th0 in cases:
+        if th0 is None:
+            th0 = truth + 0.01 * g.standard_normal((150, 12))
+            th0[:, :5] = np.sort(th0[:, :5], axis=1)
+        Ne, T = th0.shape[0], 16
+        betas = 0.7 ** np.arange(K)
+        pt = PTSampler(m, mkp(m), th0, betas=betas, Pswap=0.3, seed=13)
+        pt.run(T)
+        S, idx = orc.pt_slots(Ne, K)
+        slots = np.zeros((S, dd))
+        slots[:] = th0[0]
+        slots[idx] = th0[:, None, :]
+        ht, hl, code, _ = orc.run_pt(om, mko(), slots, orc.rng_seed(13, S), T, betas, 0.3)
+        np.testing.assert_array_equal(pt._host_codes, code[:, idx], err_msg=name)
+        np.testing.assert_allclose(pt._host_thetas, ht[:, idx], rtol=1e-8, atol=1e-10, err_msg=name)
+        np.testing.assert_allclose(pt._host_logpost, hl[:, idx], rtol=1e-8, err_msg=name)
+        # (pCN pulls towards the origin, where the changepoint posterior has no mass: its within-chain
+        # moves are all rejected there, which is the parity case that matters for that model)
+        assert (code[:, idx] == 3).sum() > 10 and ((code[:, idx] == 1).sum() > 50 or name == "pcn changepoint"), name
+    with pytest.raises(ra.ParameterError):
+        PTSampler(MultiGaussianDist(np.zeros(2), np.eye(2)), AdaptScaleRandomWalk(np.eye(2)), np.zeros((4, 2))).run(3)

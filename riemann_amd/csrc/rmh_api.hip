@@ -536,6 +536,44 @@ int rmh_model_logreg_create(const double *X, const double *y, int64_t n, int d, 
     return RMH_OK;
 }
 
+// Sufficient statistics of the changepoint likelihood (k_cp_rw_ss, k_cp_rw_ss64, k_cprj_run): with x
+// sorted, the data of piece p are a contiguous run, so sum (ypred - y)^2 needs only the run
+// boundaries (searches) and prefix sums of y.  Leaves a.ss_xp null when n is too large for the LDS.
+static int build_cp_ss(rmh_model *m, CpArgs &a, const double *x, const double *y, int n)
+{
+    a.ss_xp = nullptr;
+    a.ss_steps = 0;
+    a.ss_ym = a.ss_p2 = 0.0;
+    if (n > 2047) return RMH_OK;
+    int steps = 1;
+    while ((2 << (steps - 1)) <= n) ++steps;          // floor(log2 n) + 1
+    const int np = (1 << steps) - 1;                  // >= n
+    std::vector<int> ord((size_t)n);
+    for (int i = 0; i < n; ++i) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int u, int v) { return x[u] < x[v]; });
+    double ym = 0.0;
+    for (int i = 0; i < n; ++i) ym += y[i];
+    ym /= n;
+    std::vector<double> xp((size_t)np + (np + 1), 0.0);
+    double p1 = 0.0, p2 = 0.0;
+    for (int i = 0; i < np; ++i) xp[i] = i < n ? x[ord[i]] : HUGE_VAL;
+    for (int i = 0; i <= np; ++i) {
+        xp[(size_t)np + i] = p1;                      // P1[i] = sum of the first i centred y
+        if (i < n) {
+            const double yc = y[ord[i]] - ym;
+            p1 += yc;
+            p2 += yc * yc;
+        }
+    }
+    int rc;
+    if ((rc = upload(&m->d_ssxp, xp.data(), xp.size()))) return rc;
+    a.ss_xp = m->d_ssxp;
+    a.ss_steps = steps;
+    a.ss_ym = ym;
+    a.ss_p2 = p2;
+    return RMH_OK;
+}
+
 int rmh_model_changepoint_create(const double *x, const double *y, int n, int k, double xmin,
                                  double xmax, double lamb, double alpha, double beta,
                                  rmh_model_t *out)
@@ -572,39 +610,9 @@ int rmh_model_changepoint_create(const double *x, const double *y, int n, int k,
     a.c_s = std::lgamma(2 * kp + 1);                      // :143
     a.c_sL = kp * std::log(xmax - xmin);
     a.nlog2pi = n * std::log(2 * M_PI);                   // :119
-    // sufficient statistics for k_cp_rw_ss: with x sorted, the data of piece p are a contiguous
-    // run, so sum (ypred - y)^2 needs only the run boundaries (searches) and prefix sums of y
-    a.ss_xp = nullptr;
-    a.ss_steps = 0;
-    if (n <= 2047) {
-        int steps = 1;
-        while ((2 << (steps - 1)) <= n) ++steps;          // floor(log2 n) + 1
-        const int np = (1 << steps) - 1;                  // >= n
-        std::vector<int> ord((size_t)n);
-        for (int i = 0; i < n; ++i) ord[i] = i;
-        std::stable_sort(ord.begin(), ord.end(), [&](int u, int v) { return x[u] < x[v]; });
-        double ym = 0.0;
-        for (int i = 0; i < n; ++i) ym += y[i];
-        ym /= n;
-        std::vector<double> xp((size_t)np + (np + 1), 0.0);
-        double p1 = 0.0, p2 = 0.0;
-        for (int i = 0; i < np; ++i) xp[i] = i < n ? x[ord[i]] : HUGE_VAL;
-        for (int i = 0; i <= np; ++i) {
-            xp[(size_t)np + i] = p1;                      // P1[i] = sum of the first i centred y
-            if (i < n) {
-                const double yc = y[ord[i]] - ym;
-                p1 += yc;
-                p2 += yc * yc;
-            }
-        }
-        if ((rc = upload(&m->d_ssxp, xp.data(), xp.size()))) {
-            rmh_model_free(m);
-            return rc;
-        }
-        a.ss_xp = m->d_ssxp;
-        a.ss_steps = steps;
-        a.ss_ym = ym;
-        a.ss_p2 = p2;
+    if ((rc = build_cp_ss(m, a, x, y, n))) {
+        rmh_model_free(m);
+        return rc;
     }
     *out = m;
     return RMH_OK;
@@ -650,6 +658,10 @@ int rmh_model_changepoint_rj_create(const double *x, const double *y, int n, int
     a.nlog2pi = n * std::log(2 * M_PI);
     m->rj.ktab = m->d_ktab;
     m->rj.KM = kmax;
+    if ((rc = build_cp_ss(m, a, x, y, n))) {
+        rmh_model_free(m);
+        return rc;
+    }
     *out = m;
     return RMH_OK;
 }

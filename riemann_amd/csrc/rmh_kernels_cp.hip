@@ -876,7 +876,12 @@ struct CpRj {
             const bool valid = j <= s.k;
             if (j == s.k) hi = b.xmax; // the last piece ends at xmax (cpx beyond k is +inf)
             const double vv = valid ? v : 1.0, dx = valid ? hi - lo : 1.0;
-            const double tv = ((b.c_v + b.alpha_m1 * log_full(vv)) - b.beta * vv) - b.lgam_alpha;
+            // (alpha - 1) log(v): with alpha = 1 the product is +-0 for 0 < v < inf and NaN otherwise,
+            // exactly as numpy evaluates it -- the same bits without the logarithm
+            double la;
+            if (b.alpha_m1 == 0.0) la = (vv > 0.0 && vv < __builtin_huge_val()) ? 0.0 : __builtin_nan("");
+            else la = b.alpha_m1 * log_full(vv);
+            const double tv = ((b.c_v + la) - b.beta * vv) - b.lgam_alpha;
             const double ts = log_full(dx);
             pv += valid ? tv : 0.0;
             ps += valid ? ts : 0.0;
@@ -929,6 +934,74 @@ struct CpRj {
         return logL;
     }
 
+    // The same likelihood from sufficient statistics (k_cp_rw_ss above has the algebra): the data of
+    // piece p are the run [B_{p-1}, B_p) of the sorted x, B_j = #{x_i <= cpx_j}; lane g searches the
+    // boundaries j = g (mod 4) and publishes (B_j, P1[B_j]) in the chain's LDS row, then every lane
+    // adds up the k + 1 pieces.  Boundaries from j = k on are clamped to (n, P1[n]): the pieces beyond
+    // k are empty by construction and need no mask (cpx beyond k is +inf, cpv beyond k + 1 is 1).
+    // O(k log n) instead of O(n k) per evaluation; sorted cpx only (an unsorted candidate has
+    // log prior -inf and its likelihood is never used).
+    template <int STEPS>
+    static RMH_DEV double log_lik_ss(const double *xs, const double *P1, double *brow, const CpRjArgs &m,
+                                     const State &s, int g)
+    {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const CpArgs &b = m.base;
+#pragma unroll
+        for (int j0 = 0; j0 < KD; j0 += 4) {
+            double key = __builtin_huge_val();
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (j0 + q < KD && g == q) key = s.cpx[j0 + q < KD ? j0 + q : 0];
+            int lo8 = 0;                                      // 8 * (entries known to be <= key)
+            if (STEPS > 0) {
+#pragma unroll
+                for (int st = STEPS - 1; st >= 0; --st) {
+                    const double xv = *reinterpret_cast<const double *>(
+                        reinterpret_cast<const char *>(xs) + lo8 + ((8 << st) - 8));
+                    lo8 += (xv <= key) ? (8 << st) : 0;
+                }
+            } else {
+                for (int st = b.ss_steps - 1; st >= 0; --st) {
+                    const int step8 = 8 << st;
+                    const double xv = *reinterpret_cast<const double *>(
+                        reinterpret_cast<const char *>(xs) + lo8 + step8 - 8);
+                    lo8 += (xv <= key) ? step8 : 0;
+                }
+            }
+            d2_t pair;
+            pair.x = (double)(lo8 >> 3);
+            pair.y = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(P1) + lo8);
+            if (j0 + g < KD) reinterpret_cast<d2_t *>(brow)[j0 + g] = pair;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes are in order
+        const double bn = (double)b.n, pn = P1[b.n];
+        double acc = 0.0, bprev = 0.0, pprev = 0.0;
+#pragma unroll
+        for (int pz = 0; pz < KP; ++pz) {
+            double bcur = bn, pcur = pn;
+            if (pz < KD) {
+                const d2_t pair = reinterpret_cast<const d2_t *>(brow)[pz];
+                bcur = pz < s.k ? pair.x : bn;
+                pcur = pz < s.k ? pair.y : pn;
+            }
+            const double vc = s.cpv[pz] - b.ss_ym;
+            acc = fma_(vc, fma_(bcur - bprev, vc, -2.0 * (pcur - pprev)), acc);
+            bprev = bcur;
+            pprev = pcur;
+            // four pairs in flight at a time: read all at once they cost 2 KP registers next to the
+            // two padded states the iteration already holds
+            if ((pz & 3) == 3) asm volatile("" ::: "memory");
+        }
+        __builtin_amdgcn_wave_barrier();                      // the row is rewritten by the next evaluation
+        const double sig2 = s.sig * s.sig;
+        const double ss = (b.ss_p2 + acc) / sig2;
+        double logL = -0.5 * ((ss + b.n * log_full(sig2)) + b.nlog2pi);
+        if (logL != logL) logL = -__builtin_huge_val();
+        return logL;
+    }
+
     static RMH_DEV void load(const double *theta, int64_t ld, int64_t c, int KM, State &s)
     {
 #pragma unroll
@@ -953,18 +1026,27 @@ struct CpRj {
     }
 };
 
-template <int KD>
-__global__ void __launch_bounds__(256) k_cprj_run(CpRjArgs m, ChainArgs ch, RunArgs run)
+// SS < 0: the O(n k) likelihood over the data in LDS; SS >= 0: from sufficient statistics
+// (CpRj::log_lik_ss; SS > 0 = the search depth as a compile-time constant, 0 = m.base.ss_steps)
+template <int KD, int SS>
+__global__ void __launch_bounds__(256, (KD <= 6 ? 3 : 2)) k_cprj_run(CpRjArgs m, ChainArgs ch, RunArgs run)
 {
     using R = CpRj<KD>;
     constexpr int KP = KD + 1;
+    constexpr int BS = 2 * (KD | 1);               // doubles per chain row of the (B, P1[B]) exchange
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int KM = m.KM, Dn = 2 * KM + 2, n = m.base.n;
-    double *xy = lds;                              // x[n], y[n]
-    double *ktab = lds + 2 * n;                    // (KM+2) x 4
+    const int np = (1 << m.base.ss_steps) - 1;     // SS >= 0: sorted x padded to np entries, then P1 (np + 1)
+    const int ndata = SS >= 0 ? 2 * np + 2 : 2 * n;
+    double *xy = lds;                              // x[n], y[n]  (SS >= 0: xs[np], P1[np + 1])
+    double *ktab = lds + ndata;                    // (KM+2) x 4
     double *tab = ktab + 4 * (KM + 2);             // inverse-CDF table (16-byte aligned: n even or padded by the host)
     double *xi_all = tab + kIcdfDoubles;           // per wave: 16 chains x 32 coordinates
-    for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) xy[i] = m.base.xy[i];
+    double *b_all = xi_all + 4 * 16 * 32;          // SS >= 0: per wave 16 chains x BS
+    if (SS >= 0)
+        for (int i = threadIdx.x; i < 2 * np + 1; i += blockDim.x) xy[i] = m.base.ss_xp[i];
+    else
+        for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) xy[i] = m.base.xy[i];
     for (int i = threadIdx.x; i < 4 * (KM + 2); i += blockDim.x) ktab[i] = m.ktab[i];
     icdf_stage(tab, ch.icdf);
     __syncthreads();
@@ -975,6 +1057,7 @@ __global__ void __launch_bounds__(256) k_cprj_run(CpRjArgs m, ChainArgs ch, RunA
     if (blk >= ch.nblocks) return;
     const int64_t c = blk * 16 + cl, slot = blk * 64 + lane;
     double *xw = xi_all + wave * (16 * 32) + cl * 32;   // this chain's normals by coordinate
+    double *brow = b_all + wave * (16 * BS) + cl * BS;
 
     typename R::State th;
     R::load(ch.theta, ch.ld, c, KM, th);
@@ -1072,7 +1155,8 @@ __global__ void __launch_bounds__(256) k_cprj_run(CpRjArgs m, ChainArgs ch, RunA
         if (mv != 5) {
             const double logP = R::log_prior(m, ktab, tp, g);
             if (__any(logP > -__builtin_huge_val())) {
-                const double logL = R::template log_lik<true>(xy, m, tp, g);
+                const double logL = SS >= 0 ? R::template log_lik_ss<SS>(xy, xy + np, brow, m, tp, g)
+                                            : R::template log_lik<true>(xy, m, tp, g);
                 lpp = combine_post(logP, logL);
             }
         }
@@ -1120,23 +1204,33 @@ __global__ void __launch_bounds__(256) k_cprj_eval(CpRjArgs m, ChainArgs ch, dou
 
 hipError_t launch_cprj_run(const CpRjArgs &m, const ChainArgs &c, const RunArgs &r, hipStream_t st)
 {
-    const int nev = (2 * m.base.n + 4 * (m.KM + 2) + 1) & ~1; // keep the table 16-byte aligned
-    (void)nev;
-    const size_t lds = sizeof(double) * ((size_t)2 * m.base.n + 4 * (m.KM + 2) + kIcdfDoubles + 4 * 16 * 32);
+    // likelihood from sufficient statistics when the model has them (n <= 2047); RMH_CPRJ_NO_SS
+    // keeps the O(n k) loop over the data (measurements, cross-checks)
+    const bool ss = m.base.ss_xp && !getenv("RMH_CPRJ_NO_SS");
+    const int np = (1 << m.base.ss_steps) - 1;
+    const size_t ndata = ss ? (size_t)2 * np + 2 : (size_t)2 * m.base.n;
+    const size_t lds = sizeof(double) * (ndata + 4 * (m.KM + 2) + kIcdfDoubles + 4 * 16 * 32 +
+                                         (ss ? 4 * 16 * 2 * (14 | 1) : 0));
     const dim3 grid((unsigned)((c.nblocks + 3) / 4)), block(256);
+#define RMH_CPRJ_LAUNCH(KD, SS)                                                                      \
+    do {                                                                                             \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cprj_run<KD, SS>),       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+        if (e != hipSuccess) return e;                                                               \
+        hipLaunchKernelGGL((k_cprj_run<KD, SS>), grid, block, lds, st, m, c, r);                     \
+    } while (0)
     if (m.KM <= 6) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cprj_run<6>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_cprj_run<6>, grid, block, lds, st, m, c, r);
+        if (!ss) RMH_CPRJ_LAUNCH(6, -1);
+        else if (m.base.ss_steps == 7) RMH_CPRJ_LAUNCH(6, 7);
+        else RMH_CPRJ_LAUNCH(6, 0);
     } else if (m.KM <= 14) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cprj_run<14>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_cprj_run<14>, grid, block, lds, st, m, c, r);
+        if (!ss) RMH_CPRJ_LAUNCH(14, -1);
+        else if (m.base.ss_steps == 7) RMH_CPRJ_LAUNCH(14, 7);
+        else RMH_CPRJ_LAUNCH(14, 0);
     } else {
         return hipErrorInvalidValue;
     }
+#undef RMH_CPRJ_LAUNCH
     return hipGetLastError();
 }
 

@@ -345,7 +345,10 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw(CpArgs m, RwArgs pr, ChainArgs
 // fixture and comparison run.
 // STEPS > 0: the search depth as a compile-time constant (the probe offsets become instruction
 // immediates: 3 instead of 5.5 vector instructions per step); 0: m.ss_steps at run time.
-template <int KC, int STEPS>
+// BLOCK: the block-mixture proposal of ChangepointRegression1DProp at fixed k (test_changepoint.py:18-56,
+// as in k_cp_rw: one more word per sub-stream after the normals, block picked by chained uniforms, the
+// normals outside the block zeroed -- with a diagonal factor the other coordinates then stay put exactly).
+template <int KC, int STEPS, bool BLOCK = false>
 __global__ void __launch_bounds__(512, 4) k_cp_rw_ss(CpArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
     constexpr int D = 2 * KC + 2, KP = KC + 1;
@@ -406,6 +409,18 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw_ss(CpArgs m, RwArgs pr, ChainA
         // ---- propose: theta' = theta + scale L xi, L diagonal (randomwalk.py:26)
         double xi[S];
         T::template normals_fixed<(D + 7) / 8, D, 1>(rng, D, g, tab, xi);
+        double ub[4] = {0.0, 0.0, 0.0, 0.0};
+        if (BLOCK) { // one word per sub-stream: (accept uniform, u_cpx, u_cpv, u_sig)
+            gather4(u01(xo_next(rng)), ub);
+            int pk = -1;
+            if (pr.nblk > 2 && ub[3] < pr.blk_p[2]) pk = 2;
+            if (pr.nblk > 1 && ub[2] < pr.blk_p[1]) pk = 1;
+            if (pr.nblk > 0 && ub[1] < pr.blk_p[0]) pk = 0;
+            const int lo = pk <= 0 ? 0 : pr.blk_end[pk == 2 ? 1 : 0];
+            const int hi = pk < 0 ? 0 : pr.blk_end[pk];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) xi[s] = (4 * s + g >= lo && 4 * s + g < hi) ? xi[s] : 0.0;
+        }
         double tp[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -441,7 +456,7 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw_ss(CpArgs m, RwArgs pr, ChainA
         // sub-stream) takes u, group 1 the product, group 2 sig^2, and an all-gather over the chain's
         // four lanes hands every lane the three results.  log_fast is log_core, operation for
         // operation the accept test's logarithm, for every positive normal argument.
-        const double uown = u01(xo_next_if(rng, g == 0));
+        const double uown = BLOCK ? ub[0] : u01(xo_next_if(rng, g == 0));
         const double larg = g == 0 ? uown : g == 1 ? prod : g == 2 ? sig2 : 1.0;
         double lg[4];
         gather4(log_fast(larg), lg);
@@ -726,7 +741,7 @@ static hipError_t cp_rw_ss_launch(const CpArgs &m, const RwArgs &p, const ChainA
     // one lane per chain (k_cp_rw_ss64: 4 waves x 64 chains per workgroup) once there are enough
     // chains to give every SIMD of the chip a wavefront of 64 (65 536: one each); below that the
     // four-lanes-per-chain kernel keeps four times as many waves in flight
-    if (getenv("RMH_CP_SS64") || (c.nblocks >= 4096 && !getenv("RMH_CP_SS16"))) {
+    if (p.nblk == 0 && (getenv("RMH_CP_SS64") || (c.nblocks >= 4096 && !getenv("RMH_CP_SS16")))) {
         constexpr int DE = 2 * ((D + 2) / 2), TS64 = 2 * ((DE / 2) | 1);
         const int nw = 4;
         const size_t lds = sizeof(double) * ((size_t)2 * np + 2 + kIcdfDoubles + (size_t)nw * 64 * TS64);
@@ -755,19 +770,23 @@ static hipError_t cp_rw_ss_launch(const CpArgs &m, const RwArgs &p, const ChainA
     const size_t lds = sizeof(double) * ((size_t)2 * np + 2 + kIcdfDoubles + (size_t)nw * 16 * (TS + BS));
     if (lds > 80 * 1024) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((c.nblocks + nw - 1) / nw));
-#define RMH_CP_SS(STEPS)                                                                          \
-    {                                                                                             \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cp_rw_ss<KC, STEPS>), \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e != hipSuccess) return e;                                                            \
-        hipLaunchKernelGGL((k_cp_rw_ss<KC, STEPS>), grid, dim3(64 * nw), lds, st, m, p, c, r);    \
-        return hipGetLastError();                                                                 \
+#define RMH_CP_SS(STEPS, BLK)                                                                          \
+    {                                                                                                  \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cp_rw_ss<KC, STEPS, BLK>), \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        if (e != hipSuccess) return e;                                                                 \
+        hipLaunchKernelGGL((k_cp_rw_ss<KC, STEPS, BLK>), grid, dim3(64 * nw), lds, st, m, p, c, r);    \
+        return hipGetLastError();                                                                      \
+    }
+    if (p.nblk > 0) { // block-mixture proposal: the cfg-5 data size as a constant, anything else at run time
+        if (m.ss_steps == 7) RMH_CP_SS(7, true)
+        RMH_CP_SS(0, true)
     }
     switch (m.ss_steps) {   // n = 32..63, 64..127 (cfg 5: n = 100), 128..255; anything else at run time
-    case 6: RMH_CP_SS(6)
-    case 7: RMH_CP_SS(7)
-    case 8: RMH_CP_SS(8)
-    default: RMH_CP_SS(0)
+    case 6: RMH_CP_SS(6, false)
+    case 7: RMH_CP_SS(7, false)
+    case 8: RMH_CP_SS(8, false)
+    default: RMH_CP_SS(0, false)
     }
 #undef RMH_CP_SS
 }

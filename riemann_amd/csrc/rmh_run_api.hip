@@ -430,9 +430,10 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
             e = launch_gauss_rw_tail(m->ga, ra, c, r, adapt, g_stream);
         } else if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
         else if (m->kind == kChangepoint && adapt) e = launch_cp_generic(m->k, m->ca, ra, c, r, 1, g_stream);
-        else if (m->kind == kChangepoint && p->nblk == 0 && p->L_is_diag && m->ca.ss_xp && m->ca.alpha_m1 == 0.0 &&
+        else if (m->kind == kChangepoint && p->L_is_diag && m->ca.ss_xp && m->ca.alpha_m1 == 0.0 &&
                  !getenv("RMH_CP_NO_SS")) {
-            // BASELINE cfg 5: diagonal proposal, alpha = 1: likelihood from sufficient statistics
+            // BASELINE cfg 5 (and the block-mixture proposal at fixed k): diagonal proposal factor,
+            // alpha = 1: likelihood from sufficient statistics
             ra.Ldiag = p->d_Ldiag;
             e = launch_cp_rw_ss(m->k, m->ca, ra, c, r, g_stream);
         } else if (m->kind == kChangepoint) e = launch_cp_rw(m->k, m->ca, ra, c, r, g_stream);

@@ -544,6 +544,8 @@ static int build_cp_ss(rmh_model *m, CpArgs &a, const double *x, const double *y
     a.ss_xp = nullptr;
     a.ss_steps = 0;
     a.ss_ym = a.ss_p2 = 0.0;
+    a.ss_nb = a.ss_s2 = 0;
+    a.ss_x0 = a.ss_invh = 0.0;
     if (n > 2047) return RMH_OK;
     int steps = 1;
     while ((2 << (steps - 1)) <= n) ++steps;          // floor(log2 n) + 1
@@ -563,6 +565,35 @@ static int build_cp_ss(rmh_model *m, CpArgs &a, const double *x, const double *y
             const double yc = y[ord[i]] - ym;
             p1 += yc;
             p2 += yc * yc;
+        }
+    }
+    // bucket table (rmh_internal.hpp, CpArgs): the smallest power of two of buckets that leaves at
+    // most 3 data points in any bucket (2 search steps), else 7 (3 steps) at 1024 buckets, else none;
+    // the probes reach 2^s2 - 2 entries beyond a bucket's first point, which the +inf padding must cover
+    const double x0 = xp[0], x1 = xp[(size_t)n - 1];
+    if (x1 > x0 && std::isfinite(x0) && std::isfinite(x1)) {
+        for (int nb = 64; nb <= 1024 && !a.ss_nb; nb *= 2) {
+            const double invh = nb / (x1 - x0);
+            std::vector<int> L((size_t)nb + 1, 0);
+            int maxw = 0;
+            for (int i = 0; i < n; ++i) {
+                const int b = (int)std::fmin(std::fmax((xp[i] - x0) * invh, 0.0), (double)(nb - 1));
+                ++L[(size_t)b + 1];
+            }
+            for (int b = 0; b < nb; ++b) {
+                maxw = std::max(maxw, L[(size_t)b + 1]);
+                L[(size_t)b + 1] += L[b];
+            }
+            const int s2 = maxw <= 3 ? 2 : (maxw <= 7 && nb == 1024) ? 3 : 0;
+            if (!s2 || np - n < (1 << s2) - 1) continue;
+            a.ss_nb = nb;
+            a.ss_s2 = s2;
+            a.ss_x0 = x0;
+            a.ss_invh = invh;
+            xp.resize((size_t)2 * np + 2 + (nb + 2) / 2 + 1, 0.0);
+            std::vector<int32_t> L8((size_t)nb + 2, 0);
+            for (int b = 0; b <= nb; ++b) L8[b] = 8 * L[b];
+            std::memcpy(xp.data() + 2 * np + 2, L8.data(), L8.size() * sizeof(int32_t));
         }
     }
     int rc;

@@ -60,6 +60,14 @@ struct CpArgs {
     const double *ss_xp;
     int ss_steps;          // steps of the branch-free upper-bound search: floor(log2 n) + 1
     double ss_ym, ss_p2;   // mean of y, sum (y_i - ym)^2
+    // bucket table in front of the searches (k_cp_rw_ss64): ss_nb uniform buckets over the data range,
+    // bucket(c) = (int)min(max((c - ss_x0) ss_invh, 0), ss_nb - 1) -- a monotone map evaluated with the
+    // same IEEE operations on the host (for the data) and on the device (for the key), so that
+    // #{x <= c} lies in [L[b], L[b+1]], L[b] = #{i : bucket(x_i) < b}.  The ss_nb + 1 entries of L
+    // (times 8: byte offsets into xs) follow the prefix sums in ss_xp as int32, from double
+    // 2 np + 2 on; ss_s2 = search steps left inside a bucket (2 or 3); ss_nb = 0: no table.
+    int ss_nb, ss_s2;
+    double ss_x0, ss_invh;
 };
 
 // Trans-dimensional changepoint sampling: model with a variable number

@@ -546,7 +546,11 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw_ss(CpArgs m, RwArgs pr, ChainA
 // no lane idles through a search it has no boundary for: per chain and iteration 14 vector
 // instructions where k_cp_rw_ss issues 26 (413 per 16 chains) and k_cp_rw 69.  History rows are
 // written by 64 consecutive chains per instruction (whole 512-byte lines).
-template <int KC, int STEPS>
+// S2 > 0: a bucket table in front of the searches (CpArgs::ss_nb, rmh_internal.hpp): one multiply-and-
+// truncate and one table read give #{x <= key} up to the (at most 2^S2 - 1) points of one bucket, which
+// S2 search steps resolve -- 1 + S2 dependent LDS round trips per boundary instead of floor(log2 n) + 1,
+// and this kernel's single wave per SIMD waits out every one of them.  Same counts, hence the same bits.
+template <int KC, int STEPS, int S2 = 0>
 __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
     constexpr int D = 2 * KC + 2, KP = KC + 1;
@@ -557,10 +561,14 @@ __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainAr
     typedef double d2_t __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int np = (1 << m.ss_steps) - 1;
+    const int bkd = S2 > 0 ? (((m.ss_nb + 2) / 2 + 1) & ~1) : 0;   // doubles of the bucket table (int32 entries)
     double *xs = lds, *P1 = lds + np;
-    double *tab = P1 + np + 2;
+    const int32_t *bk = reinterpret_cast<const int32_t *>(lds + 2 * np + 2);
+    double *tab = P1 + np + 2 + bkd;
     double *xch = tab + kIcdfDoubles;            // per wave: 64 rows of TS doubles
     for (int i = threadIdx.x; i < 2 * np + 1; i += blockDim.x) lds[i] = m.ss_xp[i];
+    if (S2 > 0)
+        for (int i = threadIdx.x; i < (m.ss_nb + 2) / 2; i += blockDim.x) lds[2 * np + 2 + i] = m.ss_xp[2 * np + 2 + i];
     icdf_stage(tab, ch.icdf);
     __syncthreads();
 
@@ -677,7 +685,22 @@ __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainAr
             int lo8[KC];
 #pragma unroll
             for (int j = 0; j < KC; ++j) lo8[j] = 0;
-            if (STEPS > 0) {
+            if (S2 > 0) {
+                const double nbm1 = (double)(m.ss_nb - 1);
+#pragma unroll
+                for (int j = 0; j < KC; ++j) {
+                    const double fb = __builtin_fmin(__builtin_fmax((tp[j] - m.ss_x0) * m.ss_invh, 0.0), nbm1);
+                    lo8[j] = bk[(int)fb];                         // 8 L[bucket]
+                }
+#pragma unroll
+                for (int sp = S2 - 1; sp >= 0; --sp)
+#pragma unroll
+                    for (int j = 0; j < KC; ++j) {
+                        const double xv = *reinterpret_cast<const double *>(
+                            reinterpret_cast<const char *>(xs) + lo8[j] + ((8 << sp) - 8));
+                        lo8[j] += (xv <= tp[j]) ? (8 << sp) : 0;
+                    }
+            } else if (STEPS > 0) {
 #pragma unroll
                 for (int sp = STEPS - 1; sp >= 0; --sp)
 #pragma unroll
@@ -744,18 +767,22 @@ static hipError_t cp_rw_ss_launch(const CpArgs &m, const RwArgs &p, const ChainA
     if (p.nblk == 0 && (getenv("RMH_CP_SS64") || (c.nblocks >= 4096 && !getenv("RMH_CP_SS16")))) {
         constexpr int DE = 2 * ((D + 2) / 2), TS64 = 2 * ((DE / 2) | 1);
         const int nw = 4;
-        const size_t lds = sizeof(double) * ((size_t)2 * np + 2 + kIcdfDoubles + (size_t)nw * 64 * TS64);
+        const bool buckets = m.ss_nb > 0 && !getenv("RMH_CP_NO_BUCKETS");
+        const size_t bkd = buckets ? (size_t)(((m.ss_nb + 2) / 2 + 1) & ~1) : 0;
+        const size_t lds = sizeof(double) * ((size_t)2 * np + 2 + bkd + kIcdfDoubles + (size_t)nw * 64 * TS64);
         if (lds <= 160 * 1024) {
             const int64_t ngrp = (c.nblocks + 3) / 4;
             const dim3 grid((unsigned)((ngrp + nw - 1) / nw));
-#define RMH_CP_SS64(STEPS)                                                                            \
-    {                                                                                                 \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cp_rw_ss64<KC, STEPS>),   \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
-        if (e != hipSuccess) return e;                                                                \
-        hipLaunchKernelGGL((k_cp_rw_ss64<KC, STEPS>), grid, dim3(64 * nw), lds, st, m, p, c, r);      \
-        return hipGetLastError();                                                                     \
+#define RMH_CP_SS64(...)                                                                                 \
+    {                                                                                                    \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cp_rw_ss64<KC, __VA_ARGS__>), \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        if (e != hipSuccess) return e;                                                                   \
+        hipLaunchKernelGGL((k_cp_rw_ss64<KC, __VA_ARGS__>), grid, dim3(64 * nw), lds, st, m, p, c, r);    \
+        return hipGetLastError();                                                                        \
     }
+            if (buckets && m.ss_s2 == 2) RMH_CP_SS64(0, 2)
+            if (buckets && m.ss_s2 == 3) RMH_CP_SS64(0, 3)
             switch (m.ss_steps) {
             case 6: RMH_CP_SS64(6)
             case 7: RMH_CP_SS64(7)

@@ -242,7 +242,7 @@ int rmh_run(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, int64_t n
  * history: bit 0 = the replica's state changed (accepted move or swap), bit 1 = the
  * replica took part in a swap proposal.  The state's log posteriors are the TEMPERED
  * ones.  Within-chain proposals: MetropolisRandomWalk and pCN (all four models), VanillaHMC / MALA
- * with or without a mass matrix (Gaussian, logistic; trajectories with the base model's gradient
+ * with or without a mass matrix (Gaussian, mixture, logistic; trajectories with the base model's gradient
  * on every rung, as the reference's shared proposal object gives).  Adaptive proposals are
  * refused (that shared object would couple the rungs of a sweep sequentially).
  * Stream use per sweep: DESIGN.md, "Parallel tempering". */

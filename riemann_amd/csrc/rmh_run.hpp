@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
 // MASS: VanillaHMC with a mass matrix M (hamiltonian.py:71-74, 80-81, 29, 36, 85-87):
 // p = chM xi;  q += eps M^-1 p with M^-1 p = V^T (V p), V = chM^-1;  K = |V p|^2 / 2.
 // The three triangular tile images are read straight from global memory (L2).
-// PT: parallel tempering with HMC within-chain moves (see k_run_rw).  As in the reference the
+// PT: parallel tempering with HMC within-chain moves (see k_run_rw; Gaussian, mixture, logistic).  As in the reference the
 // proposal integrates with the gradient callable it was given -- the BASE model's, whatever
 // the rung (samplers/ptsampler.py:82 hands every rung the same proposal) -- and only the accept
 // test sees the tempered posterior.  A swap exchanges the two replicas' states and cached

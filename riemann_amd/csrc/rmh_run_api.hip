@@ -351,7 +351,7 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         if ((p->kind != kRW && p->kind != kHMC && p->kind != kPCN) || adapt || p->acov || p->nblk > 0)
             return fail(RMH_ERR_PARAM, "run_pt: built for MetropolisRandomWalk, pCN and VanillaHMC / MALA "
                                        "within-chain moves (no adaptation)");
-        if (p->kind == kHMC && m->kind != kGauss && m->kind != kLogReg)
+        if (p->kind == kHMC && m->kind != kGauss && m->kind != kLogReg && m->kind != kMixture)
             return fail(RMH_ERR_PARAM, "run_pt: this model has no gradient");
         std::vector<double> b((size_t)s->ld, 1.0);
         const int used = (16 / K) * K;
@@ -390,8 +390,9 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         if ((rc = run_adaptcov(m, p, s, c, T, r.nburn, r.nthin, need_last ? &sink : h, &launches))) return rc;
     } else if (K > 0 && p->kind == kHMC) {
         HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT, p->minv};
-        e = m->kind == kGauss ? launch_gauss_hmc(m->NT, m->ga, ha, c, r, false, g_stream)
-                              : launch_logreg_hmc(m->NT, m->la, ha, c, r, false, g_stream);
+        e = m->kind == kGauss     ? launch_gauss_hmc(m->NT, m->ga, ha, c, r, false, g_stream)
+            : m->kind == kMixture ? launch_mix_hmc(m->NT, m->ma, ha, c, r, false, g_stream)
+                                  : launch_logreg_hmc(m->NT, m->la, ha, c, r, false, g_stream);
     } else if (K > 0 && p->kind == kPCN) {
         RwArgs ra{p->d_Ltiles, p->d_V, p->rho};
         e = m->kind == kGauss         ? launch_gauss_pcn(m->NT, m->ga, ra, c, r, false, g_stream)

@@ -172,9 +172,13 @@ def test_parallel_tempering_with_pcn_and_mass_matrix_hmc_within_the_rungs(ra, or
         ("mala mass logreg", LogisticRegression(X, y, 100.0), orc.LogReg(X, y, 100.0), 24,
          lambda m: VanillaHMC(0.3, 1, m, M=Mm), lambda: orc.HMC(0.3, 1, 24, M=Mm), 4, 0.3 * g.standard_normal((150, 24))),
     ]
-    if omix is not None:
-        cases.append(("pcn mixture", mix, omix, 2, lambda m: pCN(1.5 * np.eye(2), 0.8), lambda: orc.PCN(1.5 * np.eye(2), 0.8),
-                      5, g.standard_normal((150, 2))))
+    cases.append(("pcn mixture", mix, omix, 2, lambda m: pCN(1.5 * np.eye(2), 0.8), lambda: orc.PCN(1.5 * np.eye(2), 0.8),
+                  5, g.standard_normal((150, 2))))
+    cases.append(("hmc mixture", mix, omix, 2, lambda m: VanillaHMC(0.3, 4, m), lambda: orc.HMC(0.3, 4, 2),
+                  5, g.standard_normal((150, 2))))
+    M2 = np.array([[2.0, 0.3], [0.3, 0.5]])
+    cases.append(("mala mass mixture", mix, omix, 2, lambda m: VanillaHMC(0.4, 1, m, M=M2), lambda: orc.HMC(0.4, 1, 2, M=M2),
+                  4, g.standard_normal((150, 2))))
     for name, m, om, dd, mkp, mko, K, th0 in cases:
         if th0 is None:
             th0 = truth + 0.01 * g.standard_normal((150, 12))

@@ -216,3 +216,47 @@ def test_trans_dimensional_changepoint_many_chains_vs_oracle(ra, orc, KM, N):
     np.testing.assert_allclose(s._chain_logpost, hl, rtol=RTOL)
     assert set(np.unique(mv)) >= {0, 1, 2, 3, 4} and (mv == 5).any()
     assert (acc[mv == 3] == 1).sum() > 20 and (acc[mv == 4] == 1).sum() > 20
+
+
+@pytest.mark.parametrize("case", ["n33", "n127_no_padding", "n500_dense", "clustered", "duplicates", "unsorted_k3"])
+def test_one_lane_per_chain_kernel_search_variants_vs_oracle(ra, orc, case):
+    """k_cp_rw_ss64 finds the piece boundaries through a bucket table (two or three search steps
+    inside a bucket) or, where the data do not allow one (no +inf padding left, clustered x), through
+    the full binary search; data sizes on both sides of the compile-time search depths, duplicate and
+    unsorted x.  Forced here (by itself the kernel takes over at 65 536 chains); states, log
+    posteriors and accept masks against the oracle's O(n) likelihood."""
+    import os
+    from riemann_amd import workloads as W
+    from riemann_amd.models import ChangepointRegression1D
+    from riemann_amd.proposals import MetropolisRandomWalk
+    g = np.random.default_rng(hash(case) % 1000)
+    k = 3 if case == "unsorted_k3" else 5
+    n = {"n33": 33, "n127_no_padding": 127, "n500_dense": 500}.get(case, 100)
+    x, y, truth, cdiag = W.changepoint_data(seed=11, k=k, n=n)
+    if case == "clustered":        # 90 points inside 1 % of the range: no bucket table can split them
+        x = np.sort(np.concatenate([1.5 + 0.02 * g.uniform(size=90), g.uniform(1.0, 3.0, size=10)]))
+        y = truth[k + np.searchsorted(truth[:k], x)] + 0.1 * g.standard_normal(n)
+    if case == "duplicates":
+        x = np.sort(np.round(x, 1))
+        y = truth[k + np.searchsorted(truth[:k], x)] + 0.1 * g.standard_normal(n)
+    if case == "unsorted_k3":
+        perm = g.permutation(n)
+        x, y = x[perm], y[perm]
+    d, N, T = 2 * k + 2, 700, 50
+    th0 = truth + 0.01 * g.standard_normal((N, d))
+    th0[:, :k] = np.sort(th0[:, :k], axis=1)
+    os.environ["RMH_CP_SS64"] = "1"
+    try:
+        s = ra.Sampler(ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=k),
+                       MetropolisRandomWalk(np.diag(cdiag)), th0, seed=4, chain0=9)
+        s.run(T)
+    finally:
+        del os.environ["RMH_CP_SS64"]
+    om = orc.Changepoint(x, y, k, 1.0, 3.0, 5.0, 1.0, 1.0)
+    th, st = th0.copy(), orc.rng_seed(4, N, chain0=9)
+    ht, hl, acc = orc.run(om, orc.RandomWalk(np.diag(cdiag)), th, om.log_posterior(th), st, T)
+    np.testing.assert_array_equal(s._chain_accept, acc)
+    np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+    fin = np.isfinite(hl)
+    np.testing.assert_allclose(s._chain_logpost[fin], hl[fin], rtol=RTOL)
+    assert 0.01 < acc.mean() < 0.95

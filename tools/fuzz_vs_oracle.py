@@ -137,10 +137,20 @@ def one(g, it):
         betas = np.sort(g.uniform(0.0, 1.0, size=K))[::-1].copy()
         pswap = float(g.uniform(0.05, 0.9))
         chain0 = 16 * int(g.integers(0, 1000))
-        hmc = kind in ("gauss", "logreg") and g.uniform() < 0.4
+        # within-chain moves: random walk, pCN (any model), HMC / MALA with or without a mass matrix
+        # (models with a gradient)
+        hmc = kind in ("gauss", "logreg", "mix") and g.uniform() < 0.5
         Lh = int(g.integers(1, 4))
-        wprop = P.VanillaHMC(0.2, Lh, m) if hmc else P.MetropolisRandomWalk(Cp)
-        oprop = orc.HMC(0.2, Lh, d) if hmc else orc.RandomWalk(Cp)
+        if hmc:
+            Mm = spd(g, d) if g.uniform() < 0.5 else None
+            wprop, oprop = P.VanillaHMC(0.2, Lh, m, M=Mm), orc.HMC(0.2, Lh, d, M=Mm)
+            desc += " mass" if Mm is not None else ""
+        elif g.uniform() < 0.4:
+            hmc = False
+            wprop, oprop = P.pCN(Cp, 0.9), orc.PCN(Cp, 0.9)
+            desc += " pcn"
+        else:
+            wprop, oprop = P.MetropolisRandomWalk(Cp), orc.RandomWalk(Cp)
         pt = PTSampler(m, wprop, th0, betas=betas, Pswap=pswap, seed=seed, chain0=chain0)
         T1 = int(g.integers(0, T + 1))
         pt.run(T1)                       # histories append across run() calls

@@ -512,10 +512,10 @@ int rmh_model_logreg_create(const double *X, const double *y, int64_t n, int d, 
         for (int k = 0; k < d; ++k) {
             const int s = k >> 2, gg = k & 3;
             const int F = ((s & 3) << 2) | gg;
-            t[s * 64 + gg * 16 + (i ^ F)] = X[row * d + k];
+            t[s * 64 + gg * 16 + (i ^ F)] = 16.0 * X[row * d + k];   // 16 X: rmh_device.hpp, logistic_lockstep
         }
-        ch[CH * XT + k2 * 32 + 2 * i] = y[row];       // (y, w) pairs: w = 1 marks a real row
-        ch[CH * XT + k2 * 32 + 2 * i + 1] = 1.0;
+        ch[CH * XT + k2 * 32 + 2 * i] = y[row] - 0.5;      // (y - 1/2, w / 16) pairs: w = 1 marks a real row
+        ch[CH * XT + k2 * 32 + 2 * i + 1] = 0.0625;
     }
     rmh_model *m = new rmh_model;
     m->kind = kLogReg;

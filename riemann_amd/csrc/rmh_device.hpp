@@ -205,18 +205,24 @@ RMH_DEV void log_fast3(double a, double b, double c, double &la, double &lb, dou
 constexpr int kLogiNI = 600, kLogiNC = 6, kLogiCell = 2 * kLogiNC, kLogiDoubles = kLogiNI * kLogiCell;
 
 // N values in lockstep: all cells' reads first, then the Horner chains alternating (as
-// normals_lockstep).  VALUE: lse = log(1 + exp(eta)) and sg = sigmoid(eta); else sg only
-// (gradient-only evaluations inside an HMC trajectory: half the cell).
+// normals_lockstep).  Outputs in the form the residual and the density term take them:
+//   qs = sigmoid(eta) - 1/2 = copysign(q(|eta|), eta)           (y - sigmoid = (y - 1/2) - qs)
+//   hv = 16 (log(1 + exp(eta)) - eta/2) = |eta16|/2 + 16 f(|eta|)  (16 (y eta - log(1+exp eta)) = (y - 1/2) eta16 - hv)
+// The argument is eta16 = 16 eta (the model stores 16 X): the cell index is its integer part as it
+// comes, and the table holds 16 f.  All scalings are powers of two: the same bits as unscaled.
+// VALUE = false: qs only (gradient-only evaluations inside an HMC trajectory: half the cell).
 template <int N, bool VALUE>
-RMH_DEV void logistic_lockstep(const double (&eta)[N], const double *tab, double (&lse)[N], double (&sg)[N])
+RMH_DEV void logistic_lockstep(const double (&eta)[N], const double *tab, double (&hv)[N], double (&qs)[N])
 {
     typedef double d2_t __attribute__((ext_vector_type(2)));
     double t[N];
     const d2_t *c[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        double u = __builtin_fabs(eta[i]) * 16.0;
-        u = (u < 599.9999999) ? u : 599.9999999;       // NaN lands on the edge cell too
+        // min(|eta16|, edge) as ONE instruction (a NaN gives the edge, or cell 0 if it was signalling: in
+        // range either way); written in C++ the compiler adds a v_max_f64 only to quiet signalling NaNs
+        double u;
+        asm("v_min_f64 %0, |%1|, %2" : "=v"(u) : "v"(eta[i]), "s"(599.9999999));
         const int idx = (int)u;
         t[i] = fma_(2.0, __builtin_amdgcn_fract(u), -1.0);
         // 96-byte cells: v_mul_u32_u24 (full rate; a plain 32-bit multiply is a quarter-rate op)
@@ -257,21 +263,11 @@ RMH_DEV void logistic_lockstep(const double (&eta)[N], const double *tab, double
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        // max(eta, 0) + f with max(eta, 0) = (eta + |eta|) / 2, exact (a compare-free form: the
-        // select compiles to two v_max_f64, the first only to quiet a signalling NaN)
-        if (VALUE) lse[i] = fma_(0.5, eta[i] + __builtin_fabs(eta[i]), f[i]);
-        sg[i] = (eta[i] >= 0.0) ? 1.0 - sv[i] : sv[i];
+        if (VALUE) hv[i] = fma_(0.5, __builtin_fabs(eta[i]), f[i]);
+        qs[i] = __builtin_copysign(sv[i], eta[i]);          // one v_bfi_b32 on the high word
     }
 }
 
-RMH_DEV void logistic_terms(double eta, const double *tab, double &lse, double &sg)
-{
-    const double e[1] = {eta};
-    double l[1], s[1];
-    logistic_lockstep<1, true>(e, tab, l, s);
-    lse = l[0];
-    sg = s[0];
-}
 
 // t <- fma(row-broadcast of lane N of c, x, t): the DPP row broadcast of v_fmac_f64
 // (row_newbcast: lane N of the own 16-lane row).  The DPP source must not have been written by

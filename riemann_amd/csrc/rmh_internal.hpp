@@ -39,7 +39,7 @@ struct LogRegArgs {
     const double *Ximg;    // stage images, see LogRegModel (rmh_models.hpp)
     int64_t nchunks;       // stages of 2 row tiles (32 data rows)
     int ks;                // ceil(d/4): k-steps of the eta contraction
-    const double *logi;    // link-function table (rmh_device.hpp, logistic_terms)
+    const double *logi;    // link-function table (rmh_device.hpp, logistic_lockstep)
     double inv_tau2;
     double two_tau2;
 };

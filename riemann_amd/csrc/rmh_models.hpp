@@ -303,7 +303,7 @@ struct LogRegModel {
             const d2_t *yw = static_cast<const d2_t *>(__builtin_assume_aligned(cur + CH * XT + k * 32, 16));
             d2_t p[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p[r] = yw[4 * r + g];           // (y, w) of data row 4r + g
+            for (int r = 0; r < 4; ++r) p[r] = yw[4 * r + g];           // (y - 1/2, w / 16) of data row 4r + g
             double xv = 0.0, a0[NG];
             if (GRAD) {
                 if (GT) xv = img[24 * 64 + toff];
@@ -327,8 +327,11 @@ struct LogRegModel {
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                // e = 16 eta (the image holds 16 X):  16 (y eta - log(1 + exp eta)) = (y - 1/2) e - hv, weight
+                // 1/16 (0 on padding rows);  y - sigmoid(eta) = (y - 1/2) - qs needs no weight: padding rows
+                // are zero rows of X, whatever multiplies them
                 if (VALUE) ll = fma_(p[r].y, fma_(p[r].x, e[r], -lse[r]), ll);
-                res[r] = p[r].y * (p[r].x - sg[r]);
+                res[r] = p[r].x - sg[r];
             }
             if (GRAD) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -396,7 +399,7 @@ struct LogRegModel {
                 grad[25] = grad[26] = grad[27] = 0.0;
             }
 #pragma unroll
-            for (int s = 0; s < S; ++s) grad[s] = grad[s] - th[s] * m.inv_tau2;
+            for (int s = 0; s < S; ++s) grad[s] = grad[s] * 0.0625 - th[s] * m.inv_tau2;   // (16 X)^T res / 16: exact
         }
     }
 };

@@ -712,7 +712,13 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
             code = swapper ? (sw_ok ? 3 : 2) : code;
         }
         if (ADAPT) ad.adapt(acc_ok, ch.adapt_target);
-        if (run.h_accept && active && g == 0) buf_store_u8(run.h_accept + t * ch.ld, ch.ld, (uint32_t)c, (uint8_t)code);
+        // (the chain index from the log-posterior offset: kept as a register of its own it is the one value
+        // that does not fit beside the evaluation and goes to scratch)
+        if (run.h_accept && active && g == 0) {
+            uint32_t cc = vo_lp;
+            asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(cc));   // opaque: the compiler would fold it back to c
+            buf_store_u8(run.h_accept + t * ch.ld, ch.ld, cc, (uint8_t)code);
+        }
     }
     if (active) {
         if (!LPMEM && g == 0) ch.logpost[c] = lp;

@@ -82,7 +82,8 @@ def test_logreg_eval_and_grad(ra, orc):
     for n, d in ((256, 16), (1000, 7), (37, 33), (2000, 100)):
         X, y = logreg_data(n, d, seed=n)
         m, o = LogisticRegression(X, y, 100.0), orc.LogReg(X, y, 100.0)
-        th = g.standard_normal((40, d)) * np.array([0.1, 1.0, 5.0, 30.0])[g.integers(0, 4, 40)][:, None]
+        # (|eta| from the table's first cell to far beyond its edge at 37.5, where the link function saturates)
+        th = g.standard_normal((60, d)) * np.array([0.1, 1.0, 5.0, 30.0, 300.0, 1e4])[g.integers(0, 6, 60)][:, None]
         np.testing.assert_allclose(m.log_posterior(th), o.log_posterior(th), rtol=RTOL)
         np.testing.assert_allclose(m.log_prior(th), o.log_prior(th), rtol=RTOL)
         np.testing.assert_allclose(m.log_likelihood(th), o.log_likelihood(th), rtol=RTOL)

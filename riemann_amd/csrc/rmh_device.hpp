@@ -224,7 +224,7 @@ RMH_DEV void logistic_lockstep(const double (&eta)[N], const double *tab, double
         double u;
         asm("v_min_f64 %0, |%1|, %2" : "=v"(u) : "v"(eta[i]), "s"(599.9999999));
         const int idx = (int)u;
-        t[i] = fma_(2.0, __builtin_amdgcn_fract(u), -1.0);
+        t[i] = __builtin_amdgcn_fract(u);              // the cells' polynomials are in frac(|eta16|) itself
         // 96-byte cells: v_mul_u32_u24 (full rate; a plain 32-bit multiply is a quarter-rate op)
         c[i] = reinterpret_cast<const d2_t *>(__builtin_assume_aligned(
             reinterpret_cast<const char *>(tab) + __umul24((unsigned)idx, (unsigned)(kLogiCell * 8)), 16));

@@ -273,8 +273,9 @@ class Sampler(object):
         """Diagnostics of the last recorded run() reduced ON THE DEVICE (the history itself stays
         there): ``mean``, ``var`` (N, d) per chain and parameter, ``acf`` (nlags, d) the
         chain-averaged autocorrelation functions, ``tau`` (d,) the integrated autocorrelation
-        times (Sokal window ``c``), ``closed`` whether the window closed within ``nlags`` lags, and
-        ``ess`` = N * n / tau.  ``nlags``: 32, 64, ... 320."""
+        times (Sokal window ``c``), ``closed`` whether the window closed within ``nlags`` lags,
+        ``ess`` = N * n / tau, and ``rhat`` (d,) the split R-hat over the 2N half-chains.
+        ``nlags``: 32, 64, ... 320."""
         from .. import diagnostics as dg
         if self._state is None or not self._hist or self._kept < 2:
             raise IndexError("history_stats: no device history (run() with at least two kept states first)")
@@ -283,8 +284,20 @@ class Sampler(object):
         _lib.call("rmh_history_reduce", self._hist, 0, n, int(nlags), mean.ctypes.data, var.ctypes.data,
                   acf.ctypes.data)
         tau, closed = dg.integrated_time_from_acf(acf, c)
-        return {"mean": mean.T, "var": var.T, "acf": acf, "tau": tau, "closed": closed,
-                "ess": N * n / np.maximum(tau, 1.0)}
+        out = {"mean": mean.T, "var": var.T, "acf": acf, "tau": tau, "closed": closed,
+               "ess": N * n / np.maximum(tau, 1.0)}
+        # split R-hat (diagnostics.split_rhat) from the per-chain moments of the two halves
+        h = n // 2
+        if h >= 2:
+            mh, vh = np.empty((2, d, N)), np.empty((2, d, N))
+            for k in range(2):
+                _lib.call("rmh_history_reduce", self._hist, k * h, (k + 1) * h, 32, mh[k].ctypes.data,
+                          vh[k].ctypes.data, None)
+            means = np.concatenate([mh[0], mh[1]], axis=1)                      # (d, 2N)
+            W = (np.concatenate([vh[0], vh[1]], axis=1) * h / (h - 1.0)).mean(axis=1)
+            B = h * means.var(axis=1, ddof=1)
+            out["rhat"] = np.sqrt(((h - 1.0) / h * W + B / h) / W)
+        return out
 
     def run_to_disk(self, prefix, Nsamples, Nburn=0, Nthin=1, chunk=1000):
         """``run(Nsamples, Nburn, Nthin)`` with the kept states streamed to disk instead of

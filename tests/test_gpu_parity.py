@@ -806,3 +806,9 @@ def test_history_stats_on_the_device_vs_numpy(ra):
     assert st["closed"].all()
     np.testing.assert_allclose(st["tau"], tau, rtol=1e-8)
     assert np.all(st["ess"] > 0)
+    np.testing.assert_allclose(st["rhat"], dg.split_rhat(x), rtol=1e-9)
+    assert np.all(np.abs(st["rhat"] - 1.0) < 0.05)
+    s.run(5)                       # six kept states: halves of three, shorter than any lag group
+    st = s.history_stats(nlags=32)
+    np.testing.assert_allclose(st["rhat"], dg.split_rhat(s._chain_thetas), rtol=1e-9)
+    np.testing.assert_allclose(st["mean"], s._chain_thetas.mean(axis=0), rtol=1e-12, atol=1e-13)

@@ -303,7 +303,13 @@ struct LogRegModel {
             const d2_t *yw = static_cast<const d2_t *>(__builtin_assume_aligned(cur + CH * XT + k * 32, 16));
             d2_t p[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p[r] = yw[4 * r + g];           // (y - 1/2, w / 16) of data row 4r + g
+            for (int r = 0; r < 4; ++r) {                               // (y - 1/2, w / 16) of data row 4r + g
+                // gradient only: the weight is not used.  Read as half of a 16-byte pair its dead upper
+                // registers are handed to the next read at once, which then has to wait for this one:
+                // four serialised LDS round trips at the head of every row tile
+                if (VALUE) p[r] = yw[4 * r + g];
+                else p[r].x = reinterpret_cast<const double *>(yw)[2 * (4 * r + g)];
+            }
             double xv = 0.0, a0[NG];
             if (GRAD) {
                 if (GT) xv = img[24 * 64 + toff];

@@ -98,11 +98,22 @@ class Sampler(object):
     def _step_mixed(self):
         """Sampler.sample (sampler.py:72-90) for all chains, plugins called as the reference calls them."""
         N = self.Nchains
+        ada = None
         if isinstance(self.proposal, DeviceProposal):
-            if hasattr(self.proposal, "_pull_adapt"):
-                raise TypeError("adaptive device proposals need a device Model")
-            thp, logq = self.proposal.propose(self._th, rng=self._rng)            # :79
-            thp, logq = np.atleast_2d(thp), np.atleast_1d(logq)
+            if self._mixed_adapt_scale():
+                # AdaptScaleRandomWalk next to a Python Model: the chains' scales live here; the device
+                # forms L xi (the proposal at theta = 0, unscaled image) and theta' = theta + scale_c (L xi)
+                # is formed as the fused kernel forms it (a product, then a sum)
+                ada = self._mx_adapt
+                lxi, logq = DeviceProposal.propose(self.proposal, np.zeros_like(self._th), rng=self._rng)
+                thp = self._th + ada[:, 2:3] * np.atleast_2d(lxi)
+                logq = np.atleast_1d(logq)
+            elif hasattr(self.proposal, "_pull_adapt") or hasattr(self.proposal, "_init_adapt_cov"):
+                raise TypeError("this adaptive device proposal needs a device Model (next to a Python Model "
+                                "only AdaptScaleRandomWalk is built)")
+            else:
+                thp, logq = self.proposal.propose(self._th, rng=self._rng)        # :79
+                thp, logq = np.atleast_2d(thp), np.atleast_1d(logq)
         else:
             out = [self.proposal.propose(row) for row in self._th]
             thp = np.stack([np.asarray(o[0], dtype=np.float64) for o in out])
@@ -119,7 +130,35 @@ class Sampler(object):
         if not isinstance(self.proposal, DeviceProposal):
             for row in self._th:
                 self.proposal.adapt(row)                                           # :88
+        elif ada is not None:   # AdaptScaleProposal.adapt per chain (adaptive.py:25-35), as rmh_run.hpp AdaptScale
+            moved = np.where((ada[:, 0] == 0.0) | ok, 1.0, 0.0)
+            ada[:, 0] += 1.0
+            ada[:, 1] += moved
+            ratio = np.exp(1.0 / ada[:, 0])
+            up = ada[:, 1] / ada[:, 0] > self.proposal.target_accept_rate
+            ada[:, 2] = np.where(up, ada[:, 2] * ratio, ada[:, 2] / ratio)
+            self._publish_mixed_adapt()
         return ok.astype(np.uint8)
+
+    def _mixed_adapt_scale(self):
+        """AdaptScaleRandomWalk (and nothing else adaptive) can run next to a Python Model."""
+        from ..proposals.randomwalk import AdaptScaleRandomWalk
+        if not isinstance(self.proposal, AdaptScaleRandomWalk):
+            return False
+        if getattr(self, "_mx_adapt", None) is None:
+            a = np.zeros((self.Nchains, 3))
+            a[:, 2] = 1.0                                                          # adaptive.py:18-23
+            self._mx_adapt = a
+        return True
+
+    def _publish_mixed_adapt(self):
+        a, p = self._mx_adapt, self.proposal
+        ns, na = a[:, 0].astype(np.int64), a[:, 1].astype(np.int64)
+        rate = np.where(ns > 0, a[:, 1] / np.maximum(a[:, 0], 1.0), 0.0)
+        if self._single:
+            p.Nsamples, p.Naccepts, p.scale, p.accept_rate = int(ns[0]), int(na[0]), float(a[0, 2]), float(rate[0])
+        else:
+            p.Nsamples, p.Naccepts, p.scale, p.accept_rate = ns, na, a[:, 2].copy(), rate
 
     def _run_mixed(self, T, nb, nt, record):
         ths, lps, acc = [self._th.copy()], [self._lp.copy()], []
@@ -359,7 +398,8 @@ class Sampler(object):
         The reference only resumes in-process (run() continues from the last state,
         sampler.py:49-50)."""
         if self._state is None:      # mixed plugins: the chains live on the host
-            np.savez(path, theta=self._th, logpost=self._lp, rng=self._rng, single=np.bool_(self._single))
+            extra = {"adapt": self._mx_adapt} if getattr(self, "_mx_adapt", None) is not None else {}
+            np.savez(path, theta=self._th, logpost=self._lp, rng=self._rng, single=np.bool_(self._single), **extra)
             return
         th, lp = np.empty((self.Nchains, self.Npars)), np.empty(self.Nchains)
         _lib.call("rmh_state_get", self._state, th.ctypes.data, lp.ctypes.data)
@@ -387,6 +427,9 @@ class Sampler(object):
         if self._state is None:
             self._th, self._lp = _lib.as_f64(z["theta"]).copy(), _lib.as_f64(z["logpost"]).copy()
             self._rng = np.ascontiguousarray(z["rng"], dtype=np.uint64)
+            if "adapt" in z.files:
+                self._mx_adapt = _lib.as_f64(z["adapt"]).copy()
+                self._publish_mixed_adapt()
             self._host_thetas, self._host_logpost = self._th[None].copy(), self._lp[None].copy()
             self._host_accept = np.zeros((0, self.Nchains), dtype=np.uint8)
             self._kept = 1

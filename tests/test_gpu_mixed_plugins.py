@@ -134,17 +134,48 @@ def test_rng_draw_is_the_fused_kernels_stream(ra):
     np.testing.assert_array_equal(u1[0], z["u"][5])
 
 
-def test_adaptive_device_proposals_refuse_python_models(ra):
-    from riemann_amd.proposals import AdaptScaleRandomWalk, AdaptScaleHMC
+def test_python_model_with_device_adaptive_scale_random_walk(ra, tmp_path):
+    """AdaptScaleRandomWalk next to a user's numpy Model: the chains' scales adapt on the host
+    (adaptive.py:25-35), the device forms L xi on the chains' stream.  Same chains as the fused run of
+    the device Gaussian with the same proposal (states to rounding: the host takes exp from numpy,
+    the kernel from the device library), adapted scales included; checkpoint / restore carries the
+    adaptation state.  The other adaptive device proposals still need a device Model."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import AdaptCovRandomWalk, AdaptScaleHMC, AdaptScaleRandomWalk
+    g = np.random.default_rng(5)
+    d, N, T = 6, 40, 120
+    A = g.standard_normal((d, d))
+    Cov, mu = A @ A.T + d * np.eye(d), g.standard_normal(d)
+    Li = np.linalg.inv(np.linalg.cholesky(Cov))
+    logdet = np.log(np.linalg.det(Cov))
 
-    class Flat(ra.Model):
+    class Gauss(ra.Model):
         def log_prior(self, theta):
             return 0.0
 
         def log_likelihood(self, theta):
-            return -0.5 * float(theta @ theta)
+            u = Li @ (theta - mu)
+            return -0.5 * (u @ u + logdet + d * np.log(2 * np.pi))
 
-    s = ra.Sampler(Flat(), AdaptScaleRandomWalk(np.eye(2)), np.zeros(2), seed=1)
+    th0 = g.standard_normal((N, d))
+    fused = ra.Sampler(MultiGaussianDist(mu, Cov), AdaptScaleRandomWalk(0.5 * Cov), th0, seed=8)
+    fused.run(T)
+    pm = AdaptScaleRandomWalk(0.5 * Cov)
+    mixed = ra.Sampler(Gauss(), pm, th0, seed=8)
+    mixed.run(70)
+    mixed.checkpoint(str(tmp_path / "mx.npz"))
+    mixed.run(T - 70)
+    np.testing.assert_array_equal(mixed._chain_accept, fused._chain_accept[70:])
+    np.testing.assert_allclose(mixed._chain_thetas, fused._chain_thetas[70:], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(pm.scale, fused.proposal.scale, rtol=1e-12)
+    np.testing.assert_array_equal(pm.Naccepts, fused.proposal.Naccepts)
+    assert np.all(pm.Nsamples == T) and pm.scale.std() > 0.01
+    again = ra.Sampler(Gauss(), AdaptScaleRandomWalk(0.5 * Cov), th0, seed=8)
+    again.restore(str(tmp_path / "mx.npz"))
+    again.run(T - 70)
+    np.testing.assert_array_equal(again._chain_thetas, mixed._chain_thetas)
+    np.testing.assert_array_equal(again.proposal.scale, pm.scale)
+    s = ra.Sampler(Gauss(), AdaptCovRandomWalk(np.eye(d)), np.zeros(d), seed=1)
     with pytest.raises(TypeError):
         s.run(2)
     with pytest.raises(TypeError):

@@ -42,8 +42,25 @@ class AdaptScaleProposal(DeviceProposal):
             self.Nsamples, self.Naccepts, self.scale, self.accept_rate = ns, na, sc, rate
 
     def propose(self, theta, rng=None):
-        raise NotImplementedError("stand-alone propose() of an adaptive proposal is not built: "
-                                  "the per-chain scale lives with the Sampler's chains")
+        """Stand-alone form for the random walk: theta + scale * (L xi) with the current ``scale`` (a
+        scalar, or one value per row of ``theta`` after a many-chain ``run``), as randomwalk.py:26
+        with the adapted scale.  The pCN- and HMC-based variants are built inside ``Sampler.run`` only."""
+        from .randomwalk import MetropolisRandomWalk, pCN
+        if not isinstance(self, MetropolisRandomWalk) or isinstance(self, pCN) or hasattr(self, "C0"):
+            raise NotImplementedError("stand-alone propose() of this adaptive proposal is not built: "
+                                      "its state lives with the Sampler's chains")
+        th = _lib.as_f64(theta)
+        single = th.ndim <= 1
+        th2 = np.atleast_2d(np.atleast_1d(th))
+        sc = np.asarray(self.scale, dtype=np.float64)
+        if sc.ndim and sc.shape[0] != th2.shape[0]:
+            raise _lib.ParameterError("scale has one value per chain of the last run: {} values, {} rows of theta"
+                                      .format(sc.shape[0], th2.shape[0]))
+        lxi, logq = DeviceProposal.propose(self, np.zeros_like(th2), rng=rng)
+        thp = th2 + (sc[:, None] if sc.ndim else sc) * np.atleast_2d(lxi)
+        if single:
+            return thp[0], float(np.atleast_1d(logq)[0])
+        return thp, np.atleast_1d(logq)
 
 
 class AdaptCovProposal(DeviceProposal):

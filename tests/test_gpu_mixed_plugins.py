@@ -180,3 +180,31 @@ def test_python_model_with_device_adaptive_scale_random_walk(ra, tmp_path):
         s.run(2)
     with pytest.raises(TypeError):
         AdaptScaleHMC(0.1, 2, lambda th: -th)
+
+
+def test_stand_alone_propose_of_the_adaptive_scale_random_walk(ra):
+    """AdaptScaleRandomWalk.propose(theta): theta + scale (L xi) with the adapted scale(s), against the
+    plain random walk carrying the same scale; the other adaptive proposals say what is not built."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import AdaptScaleRandomWalk, AdaptScalepCN, MetropolisRandomWalk
+    from riemann_amd.rng import rng_seed_host
+    g = np.random.default_rng(9)
+    d, N = 5, 33
+    A = g.standard_normal((d, d))
+    Cov = A @ A.T + d * np.eye(d)
+    p = AdaptScaleRandomWalk(Cov)
+    th = g.standard_normal((N, d))
+    q = MetropolisRandomWalk(Cov)
+    a, la = p.propose(th, rng=rng_seed_host(3, N, 0))                 # scale = 1.0 before any run
+    b, lb = q.propose(th, rng=rng_seed_host(3, N, 0))
+    np.testing.assert_allclose(a, b, rtol=1e-14, atol=1e-14)
+    s = ra.Sampler(MultiGaussianDist(np.zeros(d), Cov), p, th, seed=2)
+    s.run(60)
+    assert np.shape(p.scale) == (N,) and np.std(p.scale) > 0
+    a, _ = p.propose(th, rng=rng_seed_host(4, N, 0))
+    step, _ = q.propose(np.zeros((N, d)), rng=rng_seed_host(4, N, 0))
+    np.testing.assert_allclose(a, th + p.scale[:, None] * step, rtol=1e-14, atol=1e-14)
+    with pytest.raises(ra.ParameterError):
+        p.propose(th[:5])
+    with pytest.raises(NotImplementedError):
+        AdaptScalepCN(Cov, 0.9).propose(th)

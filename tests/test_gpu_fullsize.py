@@ -82,6 +82,35 @@ def test_cfg5_changepoint_full_size_properties(ra):
     assert 0.05 < acc.mean() < 0.9
 
 
+def test_cfg5_block_mixture_and_trans_dimensional_proposals_full_size_properties(ra):
+    """The reference's own changepoint proposals at the bench size, on the sufficient-statistics
+    kernels: the block mixture at fixed k and the sampler over the number of changepoints."""
+    from riemann_amd.models import ChangepointParams, ChangepointRegression1D
+    from riemann_amd.proposals import ChangepointRegression1DProp
+    from riemann_amd.workloads import changepoint_data
+    x, y, truth, _ = changepoint_data()
+
+    def block():
+        th0 = truth + 0.01 * np.random.default_rng(6).standard_normal((N, 12))
+        th0[:, :5] = np.sort(th0[:, :5], axis=1)
+        m = ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=5)
+        p = ChangepointRegression1DProp(m, 2.0)
+        p.scale = 0.5
+        return m, p, th0
+
+    acc = _properties(ra, block, 60, 45, 3)
+    assert 0.02 < acc.mean() < 0.9
+
+    def rj():
+        m = ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, variable_k=True)
+        p = ChangepointRegression1DProp(m, 2.0)
+        th0 = m.pack_padded([ChangepointParams([2.0], [1.0, 3.0], 0.1)] * N)
+        return m, p, th0
+
+    acc = _properties(ra, rj, 60, 45, 3)
+    assert 0.01 < (acc & 1).mean() < 0.9
+
+
 @pytest.mark.parametrize("L,eps,T", [(1, 0.175, 5), (4, 0.12, 2)])
 def test_logistic_10000x100_vs_oracle_with_eight_live_waves(ra, orc, L, eps, T):
     """512 chains = four full workgroups of eight waves on the cfg3/cfg4 data against the oracle."""

@@ -276,6 +276,10 @@ def measure(name, a, ranks, steps, warmup, iters=0, with_cpu=True, with_ess=True
         step_end.append(time.perf_counter())
     ranks.barrier()
     dt = ranks.max(time.perf_counter() - t0)
+    # the dominant kernel's launch time: mean over this rank's launches; over the ranks the slowest one
+    # prices the roofline (and the fastest is printed beside it)
+    kms = float(np.mean(kernel_ms))
+    kms_lo, kms_hi = (-ranks.max(-kms), ranks.max(kms)) if world > 1 else (kms, kms)
 
     # pool the final states of all ranks over RCCL (diagnostics only, untimed): the library's own
     # communicator, device-resident state blocks -> one ncclAllGather + one ncclAllReduce
@@ -301,7 +305,7 @@ def measure(name, a, ranks, steps, warmup, iters=0, with_cpu=True, with_ess=True
         N = N * K                # replicas: every one makes a within-chain or a swap move per sweep
     total_iters = world * N * iters * steps
     value = total_iters / dt
-    kms = float(np.mean(kernel_ms))
+    kms = kms_hi
     flops = w["flops"] * N * iters
     bytes_ = (w["bytes"] * (0 if a.no_record else 1)) * N * iters + 16 * (d + 1) * N
     if w["bound"] == "mfma":
@@ -318,6 +322,7 @@ def measure(name, a, ranks, steps, warmup, iters=0, with_cpu=True, with_ess=True
                    "parallelism": "chains sharded by global id, %d rank(s)" % world},
         "roofline": {"bound": w["bound"], "achieved": ach, "peak": peak, "unit": unit,
                      "frac": ach / peak, "traffic": (tr * N * iters if tr else None), "kernel_ms": kms,
+                     "kernel_ms_over_ranks": [kms_lo, kms_hi],
                      "step_wall_ms": [round((b - a_) * 1e3, 3) for a_, b in zip([t0] + step_end, step_end)],
                      "algorithmic_bytes": bytes_,
                      "hbm_algorithmic_GBps": bytes_ / (kms * 1e-3) / 1e9,

@@ -22,7 +22,7 @@
  *    Model.log_posterior (models/model.py:49-52: nan or +-inf -> -inf) and the
  *    accept rule of Sampler.sample (samplers/sampler.py:83-84).
  *  - one device per process (rmh_init); handles are not thread-safe.
- *  - random numbers: the "rmh-rng v3" stream, keyed by
+ *  - random numbers: the "rmh-rng v4" stream, keyed by
  *    (seed, GLOBAL chain id); it replaces the process-global np.random used at
  *    proposals/randomwalk.py:25, proposals/hamiltonian.py:79, samplers/sampler.py:84.
  */

@@ -144,7 +144,7 @@ def olog(x):
 
 
 def normal_from_half(h):
-    """The standard normal that the 32-bit half word ``h`` of a stream word maps to (rmh-rng v3)."""
+    """The standard normal that the 32-bit half word ``h`` of a stream word maps to (rmh-rng v4)."""
     return lib().orc_normal_from_half(int(h))
 
 

@@ -31,7 +31,7 @@
 #endif
 
 /* ------------------------------------------------------------------------- */
-/* 1. "rmh-rng v3": 4 xoshiro256++ sub-streams per chain                       */
+/* 1. "rmh-rng v4": 4 xoshiro256++ sub-streams per chain                       */
 /* ------------------------------------------------------------------------- */
 /*
  * The reference draws from numpy's process-global MT19937:
@@ -136,7 +136,7 @@ double orc_log(double x)
     return dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
 }
 
-/* ---- two standard normals per 64-bit word: table-driven inverse CDF ("rmh-rng v3") ----
+/* ---- two standard normals per 64-bit word: table-driven inverse CDF ("rmh-rng v4") ----
  * (tools/gen_icdf_table.py documents the construction of the table; this file's own copy is
  * oracle/rmh_icdf_table.h; rows 0..31 of it are used)
  * Each 32-bit half h of a stream word (high half first) gives one normal:
@@ -144,10 +144,12 @@ double orc_log(double x)
  *   cell = 8 r + N[30:28];  v = 1 + N[27:1] 2^-27;  t = 2 v - 3
  *   z = Horner_fma(cell polynomial, t), negated when sign is set
  * i.e. the tail probability p = 2^(-2-r) (1 + (cell + (t+1)/2)/8) read off the half word,
- * mapped through the normal quantile: exact to 2.1e-16 as a map, on a lattice of 2^-27 in p
+ * mapped through the normal quantile by the cell's degree-6 polynomial (2.3e-12 as a map: three
+ * orders below the spacing of the lattice it is evaluated on), on a lattice of 2^-27 in p
  * within a cell (coarser in the last rows, which have few bits left) and out to |z| = 6.4 (p >= 2^-33) -- what a 32-bit generator offers.
- * (v2 spent a whole 64-bit word per normal; on MI355X the stream is the largest VALU cost of
- * the random-walk kernels and f64 MFMA shares the VALU's FP64 units: DESIGN.md section 3.)   */
+ * (v2 spent a whole 64-bit word per normal, v3 a degree-10 polynomial per normal; on MI355X the
+ * stream is the largest VALU cost of the random-walk kernels and f64 MFMA shares the VALU's FP64
+ * units: DESIGN.md section 3.)   */
 #include "rmh_icdf_table.h"
 #define ORC_ICDF_RMAX 31
 

@@ -337,15 +337,15 @@ int rmh_init(int device)
         RMH_HIP(hipEventCreateWithFlags(&g_cp_ready[k], hipEventDisableTiming));
         RMH_HIP(hipEventCreateWithFlags(&g_cp_done[k], hipEventDisableTiming));
     }
-    {   // inverse-normal-CDF table of the random stream, padded to a 96-byte cell stride
-        static_assert(RMH_ICDF_ROWS == 56 && RMH_ICDF_SUB == 8 && RMH_ICDF_NC == 11, "table shape");
-        // 96-byte cell stride, rows 16 B longer than their cells (kIcdfRowStride, rmh_device.hpp)
-        const int row_stride = RMH_ICDF_SUB * 12 + 2;
+    {   // inverse-normal-CDF table of the random stream, padded to an 80-byte cell stride
+        static_assert(RMH_ICDF_ROWS == 56 && RMH_ICDF_SUB == 8 && RMH_ICDF_NC == 7, "table shape");
+        // kIcdfStride, kIcdfRowStride of rmh_device.hpp
+        const int cell_stride = 10, row_stride = RMH_ICDF_SUB * cell_stride;
         std::vector<double> pad((size_t)RMH_ICDF_ROWS * row_stride, 0.0);
         for (int r = 0; r < RMH_ICDF_ROWS; ++r)
             for (int j = 0; j < RMH_ICDF_SUB; ++j)
                 for (int k = 0; k < RMH_ICDF_NC; ++k)
-                    pad[(size_t)r * row_stride + j * 12 + k] =
+                    pad[(size_t)r * row_stride + j * cell_stride + k] =
                         rmh_icdf_table[(r * RMH_ICDF_SUB + j) * RMH_ICDF_NC + k];
         int rc = upload(&g_icdf, pad.data(), pad.size());
         if (rc) return rc;

@@ -1,6 +1,6 @@
 // rmh_device.hpp -- device-side random stream and elementary functions (gfx950).
 //
-// "rmh-rng v3" (Random stream): chain c owns four xoshiro256++
+// "rmh-rng v4" (Random stream): chain c owns four xoshiro256++
 // sub-streams g = 0..3 (stream id 4c+g).  In the MFMA kernels the four lanes
 // {cl, cl+16, cl+32, cl+48} of a wavefront hold one chain and lane group g owns
 // sub-stream g and the coordinates j = g (mod 4) -- exactly the B-operand
@@ -280,24 +280,27 @@ RMH_DEV void fmac_bcast(double &t, double c, double x)
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(c), "v"(x), "n"(N));
 }
 
-// ---- two standard normals per 64-bit word: table-driven inverse CDF (rmh-rng v3)
+// ---- two standard normals per 64-bit word: table-driven inverse CDF (rmh-rng v4)
 // Each 32-bit half h of a stream word (high half first) gives one normal:
 //   sign = h & 1;  q = h | 1;  r = clz32(q) (<= 31);  N = (q << r) | 2^31
 //   cell = 8 r + N[30:28];  v = 1 + N[27:1] 2^-27;  t = 2 v - 3
-//   z = Horner_fma(cell polynomial of degree 10, t), sign applied by xor
+//   z = Horner_fma(cell polynomial of degree 6, t), sign applied by xor
 // i.e. the tail probability p = 2^(-2-r) (1 + (cell + (t+1)/2)/8) the half word encodes, through
-// the normal quantile: exact to 2.1e-16 as a map, on a lattice of 2^-27 in p within a cell, out
-// to |z| = 6.4.  No division, square root or trigonometry: 11 fma + ~12 integer operations per
-// normal and HALF a xoshiro step (v2 spent a whole 64-bit word per normal: 57 instructions per
-// normal against 42; on this chip f64 MFMA and VALU share the FP64 units, so every VALU cycle
-// counts -- cfg2 38.1 -> 35.4 ms).
-// The table (tools/gen_icdf_table.py, worst error 2.1e-16 relative; rows 0..31 of it) is staged
-// in LDS with a 96-byte cell stride: five ds_read_b128 and one ds_read_b64 per normal.
-// Rows are 16 B longer than their 8 cells so that the cells of rows r and r+1
-// (3/4 of all draws) fall on disjoint LDS banks.
-constexpr int kIcdfRows = 32, kIcdfSub = 8, kIcdfNC = 11, kIcdfStride = 12;
-constexpr int kIcdfRowStride = kIcdfSub * kIcdfStride + 2;        // doubles
-constexpr int kIcdfDoubles = kIcdfRows * kIcdfRowStride;          // 3136 = 25 088 B
+// the normal quantile, on a lattice of 2^-27 in p within a cell, out to |z| = 6.4.  The cell
+// polynomial reproduces the quantile to 2.3e-12 (tools/gen_icdf_table.py) -- three orders below the
+// spacing of the lattice it is evaluated on (~1e-9 in z), so the draws are the lattice's quantiles for
+// every statistical purpose; v3 carried degree 10 (2.1e-16), four more fma and two more 16-byte table
+// reads per normal that bought nothing the 32-bit input could express (cfg2 +4 %, cfg5 +8 %).
+// No division, square root or trigonometry: 7 fma + ~12 integer operations per normal and HALF a
+// xoshiro step (v2 spent a whole 64-bit word per normal).  On this chip f64 MFMA and VALU share the
+// FP64 units, so every VALU cycle counts.
+// The table (rows 0..31 of the generator's 56) is staged in LDS with an 80-byte cell stride: three
+// ds_read_b128 and one ds_read_b64 per normal.  20-dword cells put the eight cells of a row on
+// disjoint 4-bank windows, and the 160-dword rows shift by 32 banks, so the cells of rows r and r+1
+// (3/4 of all draws) are disjoint too.
+constexpr int kIcdfRows = 32, kIcdfSub = 8, kIcdfNC = 7, kIcdfStride = 10;
+constexpr int kIcdfRowStride = kIcdfSub * kIcdfStride;            // doubles
+constexpr int kIcdfDoubles = kIcdfRows * kIcdfRowStride;          // 2560 = 20 480 B
 
 RMH_DEV void icdf_stage(double *lds_tab, const double *glb_tab)
 {
@@ -306,7 +309,7 @@ RMH_DEV void icdf_stage(double *lds_tab, const double *glb_tab)
 
 // N normals in lockstep (the halves of one or two stream words): all cells' table reads first,
 // then the N Horner chains alternating.  Evaluated one after the other (what the compiler makes
-// of separate normal_from_half calls) every normal exposes its LDS latency and ten dependent
+// of separate normal_from_half calls) every normal exposes its LDS latency and six dependent
 // fma latencies.  Same operations per normal, in the same order: the same bits.
 template <int N>
 RMH_DEV void normals_lockstep(const uint32_t (&h)[N], const double *tab, double (&z)[N])
@@ -327,14 +330,15 @@ RMH_DEV void normals_lockstep(const uint32_t (&h)[N], const double *tab, double 
     // (the leading coefficient as ONE double: read as half of a 16-byte pair its unused upper
     // registers get reused at once, and the next read then has to wait for this one)
 #pragma unroll
-    for (int i = 0; i < N; ++i) z[i] = reinterpret_cast<const double *>(c[i])[10];
-    d2_t a[N][5];
+    for (int i = 0; i < N; ++i) z[i] = reinterpret_cast<const double *>(c[i])[kIcdfNC - 1];
+    constexpr int NPAIR = (kIcdfNC - 1) / 2;
+    d2_t a[N][NPAIR];
 #pragma unroll
-    for (int k = 4; k >= 0; --k)
+    for (int k = NPAIR - 1; k >= 0; --k)
 #pragma unroll
         for (int i = 0; i < N; ++i) a[i][k] = c[i][k];
 #pragma unroll
-    for (int k = 4; k >= 0; --k) {
+    for (int k = NPAIR - 1; k >= 0; --k) {
 #pragma unroll
         for (int i = 0; i < N; ++i) z[i] = fma_(z[i], t[i], a[i][k].y);
 #pragma unroll

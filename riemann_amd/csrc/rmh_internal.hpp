@@ -137,7 +137,7 @@ struct HmcArgs {
 
 // logistic model: row tiles (of 16 data rows) per LDS stage and doubles per stage image
 // (LogRegModel, rmh_models.hpp); the y / weight block of a stage is CH x 32 <= 128 doubles
-constexpr int kLogRegCH = 2; // 3 fits the LDS since the v3 table but was measured slower (MALA 0.63 -> 0.41: spills)
+constexpr int kLogRegCH = 2; // 3 was measured slower in round 1 (MALA 0.63 -> 0.41: spills)
 constexpr int kChunkDoubles(int NT) { return kLogRegCH * 256 * NT + 128; }
 
 // tile counts of the triangular images

@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) k_big_rw(GaussArgs m, RwArgs pr, ChainArg
 
     for (int64_t t = 0; t < run.T; ++t) {
         asm volatile("" ::: "memory"); // nothing of an iteration is hoisted out of the loop
-        // 1. waves 0..CB-1: the iteration's normals of their block (two per word, rmh-rng v3)
+        // 1. waves 0..CB-1: the iteration's normals of their block (two per word, rmh-rng v4)
         if (w < CB) {
             double *Yw = Y + jw * ystride;
             for (int mm = 0; mm < ch.M; ++mm) { // Y[s] is coordinate 4s + g: halves of word mm -> s = 2mm, 2mm+1

@@ -154,7 +154,7 @@ struct Tile {
 
     // S normals for this lane: Mw = ceil(d/8) words of the lane's sub-stream, two normals per
     // word -- the high half of word m is coordinate 8m+g (register 2m), the low half 8m+4+g
-    // (register 2m+1); zero beyond d (rmh-rng v3).  tab = ICDF table in LDS.
+    // (register 2m+1); zero beyond d (rmh-rng v4).  tab = ICDF table in LDS.
     // Groups of 4 normals (2 words): the xoshiro steps are a serial chain, the four table
     // evaluations of a group are branch-free so that their LDS latencies and Horner chains
     // overlap (a single evaluation is latency-bound, ~400 cycles).

@@ -1,4 +1,4 @@
-"""Host-side seeding of the "rmh-rng v3" stream (Random stream):
+"""Host-side seeding of the "rmh-rng v4" stream (Random stream):
 integer-only (splitmix64 mixing), used to create the (N,16) uint64 state that
 the stand-alone ``propose`` entry point advances on the device.  The chains of
 a Sampler are seeded on the device by ``rmh_state_create``."""

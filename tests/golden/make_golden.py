@@ -9,7 +9,7 @@ What it does: imports rscalzo/riemann from /root/reference, replaces
 ``np.random.normal`` / ``np.random.uniform`` (looked up at call time at
 riemann/proposals/randomwalk.py:25, riemann/proposals/hamiltonian.py:79 and
 riemann/samplers/sampler.py:84) by functions that replay the build's own
-"rmh-rng v3" stream (oracle/rmh_oracle.c section 1), runs the reference's
+"rmh-rng v4" stream (oracle/rmh_oracle.c section 1), runs the reference's
 ``Sampler`` once per chain and records inputs and outputs as small ``.npz``
 files.  Only data is written: no reference source text is stored.
 

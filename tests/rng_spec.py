@@ -1,4 +1,4 @@
-"""Pure-Python restatement of the "rmh-rng v3" stream (oracle/rmh_oracle.c
+"""Pure-Python restatement of the "rmh-rng v4" stream (oracle/rmh_oracle.c
 section 1; DESIGN.md "Random stream"): Python integers for xoshiro256++ and
 exact rational arithmetic for every fma, so that it shares no code and no
 floating-point library with the C oracle or the HIP kernels.  Slow: tests only.
@@ -96,7 +96,7 @@ def table():
 
 
 def normal_from_half(h):
-    """rmh-rng v3: one standard normal per 32-bit half of a stream word
+    """rmh-rng v4: one standard normal per 32-bit half of a stream word
     (tools/gen_icdf_table.py; rows 0..31 of the table)."""
     tab = table()
     q = h | 1

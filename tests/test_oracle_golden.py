@@ -174,7 +174,9 @@ def test_inverse_cdf_normals_are_accurate():
         N = ((q << r) & (2 ** 32 - 1)) | 2 ** 31
         p = (N >> 1) / 2.0 ** 30 * 2.0 ** (-2 - r)          # = 2^(-2-r) (1 + j/8 + m27 2^-30)
         ref = norm.isf(p)
-        assert abs(abs(z) - ref) <= 4e-15 * max(1.0, ref), (h, z, ref)
+        # v4: degree-6 cell polynomials, 2.3e-12 as a map (tools/gen_icdf_table.py) -- the lattice the 32-bit
+        # half word puts the probabilities on is three orders coarser (about 1e-9 in z)
+        assert abs(abs(z) - ref) <= 4e-12 * max(1.0, ref), (h, z, ref)
         assert (z < 0) == bool(h & 1) or z == 0
     # symmetric by construction: the sign is bit 0, which the magnitude ignores
     assert orc.normal_from_half(12345 * 2) == -orc.normal_from_half(12345 * 2 + 1)

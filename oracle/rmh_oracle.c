@@ -141,8 +141,8 @@ double orc_log(double x)
  * oracle/rmh_icdf_table.h; rows 0..31 of it are used)
  * Each 32-bit half h of a stream word (high half first) gives one normal:
  *   sign = h & 1;  q = h | 1;  r = min(clz32(q), 31) = clz32(q);  N = (q << r) | 2^31
- *   cell = 8 r + N[30:28];  v = 1 + N[27:1] 2^-27;  t = 2 v - 3
- *   z = Horner_fma(cell polynomial, t), negated when sign is set
+ *   cell = 8 r + N[30:28];  m = N[27:1]  (t = m 2^-26 - 1 in [-1, 1))
+ *   z = Horner_fma(cell polynomial in m, t's affine map folded into the coefficients), negated when sign is set
  * i.e. the tail probability p = 2^(-2-r) (1 + (cell + (t+1)/2)/8) read off the half word,
  * mapped through the normal quantile by the cell's degree-6 polynomial (2.3e-12 as a map: three
  * orders below the spacing of the lattice it is evaluated on), on a lattice of 2^-27 in p
@@ -161,8 +161,7 @@ double orc_normal_from_half(uint32_t h)
     const uint32_t N = (q << r) | 0x80000000u;
     const int j = (int)(N >> 28) & 7;
     const u64 m27 = (N >> 1) & 0x7FFFFFFu;
-    const double v = orc_from_bits(0x3FF0000000000000ULL | (m27 << 25));
-    const double t = fma(2.0, v, -3.0);
+    const double t = (double)m27; /* the table's polynomials are in m27 itself (t = m27 2^-26 - 1 folded in) */
     const double *c = rmh_icdf_table + (size_t)(r * RMH_ICDF_SUB + j) * RMH_ICDF_NC;
     double z = c[RMH_ICDF_NC - 1];
     for (int k = RMH_ICDF_NC - 2; k >= 0; k--) z = fma(z, t, c[k]);

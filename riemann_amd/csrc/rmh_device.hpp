@@ -283,8 +283,8 @@ RMH_DEV void fmac_bcast(double &t, double c, double x)
 // ---- two standard normals per 64-bit word: table-driven inverse CDF (rmh-rng v4)
 // Each 32-bit half h of a stream word (high half first) gives one normal:
 //   sign = h & 1;  q = h | 1;  r = clz32(q) (<= 31);  N = (q << r) | 2^31
-//   cell = 8 r + N[30:28];  v = 1 + N[27:1] 2^-27;  t = 2 v - 3
-//   z = Horner_fma(cell polynomial of degree 6, t), sign applied by xor
+//   cell = 8 r + N[30:28];  m = N[27:1]  (t = m 2^-26 - 1 in [-1, 1))
+//   z = Horner_fma(cell polynomial of degree 6 in m, coefficients with t's affine map folded in), sign by xor
 // i.e. the tail probability p = 2^(-2-r) (1 + (cell + (t+1)/2)/8) the half word encodes, through
 // the normal quantile, on a lattice of 2^-27 in p within a cell, out to |z| = 6.4.  The cell
 // polynomial reproduces the quantile to 2.3e-12 (tools/gen_icdf_table.py) -- three orders below the
@@ -323,8 +323,9 @@ RMH_DEV void normals_lockstep(const uint32_t (&h)[N], const double *tab, double 
         const int r = __builtin_clz(q);
         const uint32_t Nn = q << r;
         const int j = (int)(Nn >> 28) & 7;
-        // t = 2 v - 3 with v = 1 + m27 2^-27, i.e. m27 2^-26 - 1: exact either way, the same bits
-        t[i] = fma_((double)((Nn >> 1) & 0x7FFFFFFu), 0x1p-26, -1.0);
+        // the cells' polynomials are in the 27-bit integer m27 itself (t = m27 2^-26 - 1 folded into the
+        // coefficients by the generator): no fma to form the argument
+        t[i] = (double)((Nn >> 1) & 0x7FFFFFFu);
         c[i] = static_cast<const d2_t *>(__builtin_assume_aligned(tab + r * kIcdfRowStride + j * kIcdfStride, 16));
     }
     // (the leading coefficient as ONE double: read as half of a 16-byte pair its unused upper

@@ -104,8 +104,7 @@ def normal_from_half(h):
     N = ((q << r) & 0xFFFFFFFF) | (1 << 31)
     j = (N >> 28) & 7
     m27 = (N >> 1) & 0x7FFFFFF
-    v = frombits(0x3FF0000000000000 | (m27 << 25))
-    t = fma(2.0, v, -3.0)
+    t = float(m27)            # the table's polynomials are in m27 itself (t = m27 2^-26 - 1 folded in)
     c = tab[r, j]
     z = float(c[-1])
     for k in range(len(c) - 2, -1, -1):

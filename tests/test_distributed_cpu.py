@@ -106,7 +106,7 @@ def _host_worker(rank, world, key, n_chains, out_dir):
     g.close()
 
 
-@pytest.mark.parametrize("world,n_chains", [(2, 24), (3, 25)])
+@pytest.mark.parametrize("world,n_chains", [(2, 24), (3, 25), (8, 67)])   # 8: the ranks of one node
 def test_host_group_rendezvous_and_pooling(tmp_path, world, n_chains):
     import multiprocessing as mp
     from oracle import oracle as orc

@@ -207,3 +207,28 @@ def test_cfg5_one_lane_per_chain_kernel_ragged_chain_counts(ra, orc, n):
     ht, hl, acc = orc.run(om, orc.RandomWalk(np.diag(cdiag), 0.1), th, lp, st, 41)
     np.testing.assert_array_equal(s._chain_accept, acc)
     np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+
+
+def test_chain_count_limit_of_the_32_bit_buffer_offsets(ra):
+    """The kernels address a (rows, chains) array through 32-bit byte offsets: (16 NT + 4) (pad16(N) + 128) 8
+    must stay below 2^32 (rmh_state_create; the + 4 rows and + 128 columns are the HMC kernels' parking
+    array).  Just below the limit a run addresses its last chains correctly (they move as the same global
+    chain ids move in a small Sampler); just above, construction fails with the library's message."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import MetropolisRandomWalk
+    d = 2                                            # one row tile: 20 rows
+    lim = (1 << 32) // (20 * 8) - 128                # chains (padded to 16) at which the product reaches 2^32
+    n_ok = (lim - 16) // 16 * 16
+    m, p = MultiGaussianDist(np.zeros(d), np.eye(d)), MetropolisRandomWalk(0.5 * np.eye(d))
+    th0 = np.zeros((n_ok, d))
+    th0[-40:] = np.arange(80, dtype=np.float64).reshape(40, 2) / 40.0
+    big = ra.Sampler(m, p, th0, seed=3)
+    big.run(5, record=False)
+    tail, _ = big.current_state()
+    tail = tail[-40:].copy()
+    del big
+    small = ra.Sampler(m, p, th0[-40:], seed=3, chain0=n_ok - 40)
+    small.run(5, record=False)
+    np.testing.assert_array_equal(small.current_state()[0], tail)
+    with pytest.raises(ra.ParameterError, match="too many chains"):
+        ra.Sampler(m, p, np.zeros((lim + 32, d)), seed=3)

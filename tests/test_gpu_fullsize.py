@@ -230,5 +230,14 @@ def test_chain_count_limit_of_the_32_bit_buffer_offsets(ra):
     small = ra.Sampler(m, p, th0[-40:], seed=3, chain0=n_ok - 40)
     small.run(5, record=False)
     np.testing.assert_array_equal(small.current_state()[0], tail)
+    # the HMC kernels park momenta in a (rows + 4, chains + 128) array behind the same offsets
+    from riemann_amd.proposals import MALA
+    big = ra.Sampler(m, MALA(0.4, m), th0, seed=4)
+    big.run(3, record=False)
+    tail = big.current_state()[0][-40:].copy()
+    del big
+    small = ra.Sampler(m, MALA(0.4, m), th0[-40:], seed=4, chain0=n_ok - 40)
+    small.run(3, record=False)
+    np.testing.assert_array_equal(small.current_state()[0], tail)
     with pytest.raises(ra.ParameterError, match="too many chains"):
         ra.Sampler(m, p, np.zeros((lim + 32, d)), seed=3)

@@ -17,7 +17,7 @@ class AdaptScaleProposal(DeviceProposal):
     per chain (scalars for a single chain)."""
 
     def _init_adapt(self, target_accept_rate):
-        if not self._h:
+        if not self._h and getattr(self, "_host_grad", None) is None:
             raise TypeError("the adaptive device proposals need a device Model (their adaptation state "
                             "lives with the chains on the GPU)")
         self.Nsamples = 0
@@ -26,7 +26,8 @@ class AdaptScaleProposal(DeviceProposal):
         self.accept_rate = 0.0
         self.target_accept_rate = target_accept_rate
         self.scale = 1.0
-        _lib.call("rmh_proposal_set_adapt", self._h, float(target_accept_rate))
+        if self._h:   # (an HMC on a Python gradient callable adapts on the host, inside the Sampler's mixed loop)
+            _lib.call("rmh_proposal_set_adapt", self._h, float(target_accept_rate))
 
     def _pull_adapt(self, state, single):
         """Refresh the public attributes from the chains' adaptation state."""
@@ -46,6 +47,10 @@ class AdaptScaleProposal(DeviceProposal):
         scalar, or one value per row of ``theta`` after a many-chain ``run``), as randomwalk.py:26
         with the adapted scale.  The pCN- and HMC-based variants are built inside ``Sampler.run`` only."""
         from .randomwalk import MetropolisRandomWalk, pCN
+        if getattr(self, "_host_grad", None) is not None:     # AdaptScaleHMC on a Python gradient callable
+            if getattr(self, "_host_scale", None) is None:
+                self._host_scale = np.atleast_1d(np.asarray(self.scale, dtype=np.float64))
+            return self._propose_host(theta, rng)
         if not isinstance(self, MetropolisRandomWalk) or isinstance(self, pCN) or hasattr(self, "C0"):
             raise NotImplementedError("stand-alone propose() of this adaptive proposal is not built: "
                                       "its state lives with the Sampler's chains")

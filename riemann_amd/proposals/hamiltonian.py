@@ -87,7 +87,10 @@ class VanillaHMC(DeviceProposal):
         _lib.call("rmh_rng_draw", self._stream(N) if rng is None else rng, N, d, 1, p.ctypes.data, None)
         p = p[0]                                                   # p ~ N(0, I), hamiltonian.py:79
         k0 = np.sum(p * p, axis=1)
-        eps = float(self.eps)
+        # AdaptScaleHMC on a Python gradient: eps = scale * eps0 per chain (hamiltonian.py:101-102); the Sampler
+        # hands the chains' scales through _host_scale
+        sc = getattr(self, "_host_scale", None)
+        eps = float(self.eps) if sc is None else (np.asarray(sc, dtype=np.float64) * float(self.eps0)).reshape(-1, 1)
         if self.chM is not None:
             p = p @ self.chM.T                                     # :80-81
             minv = lambda v: np.linalg.solve(self.M, v.T).T        # noqa: E731   :29, :36
@@ -123,13 +126,14 @@ class AdaptScaleHMC(AdaptScaleProposal, VanillaHMC):
     """HMC whose step size is eps = scale * eps0 with the scale adapted towards an
     accept rate of 0.75 (hamiltonian.py:94-104), per chain."""
 
-    def __init__(self, eps, Nsteps, gradlogpost, M=None):
-        VanillaHMC.__init__(self, eps, Nsteps, gradlogpost, M=M)
+    def __init__(self, eps, Nsteps, gradlogpost, M=None, Npars=None, batched=False):
+        VanillaHMC.__init__(self, eps, Nsteps, gradlogpost, M=M, Npars=Npars, batched=batched)
         self._init_adapt(0.75)
         self.eps0 = self.eps
 
     def _sync(self):
-        _lib.call("rmh_proposal_set_eps", self._h, float(self.eps0))
+        if self._h:
+            _lib.call("rmh_proposal_set_eps", self._h, float(self.eps0))
 
 
 class AdaptCovHMC(AdaptCovProposal, VanillaHMC):

@@ -100,7 +100,13 @@ class Sampler(object):
         N = self.Nchains
         ada = None
         if isinstance(self.proposal, DeviceProposal):
-            if self._mixed_adapt_scale():
+            if self._mixed_adapt_hmc_host():
+                # AdaptScaleHMC on a Python gradient: the trajectory and the chains' scales on the host
+                ada = self._mx_adapt
+                self.proposal._host_scale = ada[:, 2]
+                thp, logq = self.proposal.propose(self._th, rng=self._rng)
+                thp, logq = np.atleast_2d(thp), np.atleast_1d(logq)
+            elif self._mixed_adapt_scale():
                 # AdaptScaleRandomWalk next to a Python Model: the chains' scales live here; the device
                 # forms L xi (the proposal at theta = 0, unscaled image) and theta' = theta + scale_c (L xi)
                 # is formed as the fused kernel forms it (a product, then a sum)
@@ -140,8 +146,20 @@ class Sampler(object):
             self._publish_mixed_adapt()
         return ok.astype(np.uint8)
 
+    def _mixed_adapt_hmc_host(self):
+        """AdaptScaleHMC on a Python gradient callable (hamiltonian.py:94-104 with a user's model)."""
+        from ..proposals.adaptive import AdaptScaleProposal
+        p = self.proposal
+        if not (isinstance(p, AdaptScaleProposal) and getattr(p, "_host_grad", None) is not None):
+            return False
+        if getattr(self, "_mx_adapt", None) is None:
+            a = np.zeros((self.Nchains, 3))
+            a[:, 2] = 1.0
+            self._mx_adapt = a
+        return True
+
     def _mixed_adapt_scale(self):
-        """AdaptScaleRandomWalk (and nothing else adaptive) can run next to a Python Model."""
+        """AdaptScaleRandomWalk can run next to a Python Model (the other adaptive device proposals cannot)."""
         from ..proposals.randomwalk import AdaptScaleRandomWalk
         if not isinstance(self.proposal, AdaptScaleRandomWalk):
             return False

@@ -141,7 +141,7 @@ def test_python_model_with_device_adaptive_scale_random_walk(ra, tmp_path):
     the kernel from the device library), adapted scales included; checkpoint / restore carries the
     adaptation state.  The other adaptive device proposals still need a device Model."""
     from riemann_amd.models import MultiGaussianDist
-    from riemann_amd.proposals import AdaptCovRandomWalk, AdaptScaleHMC, AdaptScaleRandomWalk
+    from riemann_amd.proposals import AdaptCovRandomWalk, AdaptScaleRandomWalk
     g = np.random.default_rng(5)
     d, N, T = 6, 40, 120
     A = g.standard_normal((d, d))
@@ -178,8 +178,6 @@ def test_python_model_with_device_adaptive_scale_random_walk(ra, tmp_path):
     s = ra.Sampler(Gauss(), AdaptCovRandomWalk(np.eye(d)), np.zeros(d), seed=1)
     with pytest.raises(TypeError):
         s.run(2)
-    with pytest.raises(TypeError):
-        AdaptScaleHMC(0.1, 2, lambda th: -th)
 
 
 def test_stand_alone_propose_of_the_adaptive_scale_random_walk(ra):
@@ -208,3 +206,39 @@ def test_stand_alone_propose_of_the_adaptive_scale_random_walk(ra):
         p.propose(th[:5])
     with pytest.raises(NotImplementedError):
         AdaptScalepCN(Cov, 0.9).propose(th)
+
+
+def test_adaptive_scale_hmc_on_a_python_gradient(ra):
+    """AdaptScaleHMC(eps, L, user_gradient) with a user's numpy Model: trajectory on the host with
+    device-drawn momenta, eps = scale * eps0 adapted per chain on the host (hamiltonian.py:94-104).
+    Same chains as the fused device run of the same target (to rounding: numpy's matrix products and
+    exp against the kernels')."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import AdaptScaleHMC
+    g = np.random.default_rng(11)
+    d, N, T = 5, 24, 60
+    A = g.standard_normal((d, d))
+    Cov, mu = A @ A.T + d * np.eye(d), g.standard_normal(d)
+    P = np.linalg.inv(Cov)
+    Li = np.linalg.inv(np.linalg.cholesky(Cov))
+    logdet = np.log(np.linalg.det(Cov))
+
+    class Gauss(ra.Model):
+        def log_prior(self, theta):
+            return 0.0
+
+        def log_likelihood(self, theta):
+            u = Li @ (theta - mu)
+            return -0.5 * (u @ u + logdet + d * np.log(2 * np.pi))
+
+    dm = MultiGaussianDist(mu, Cov)
+    th0 = mu + g.standard_normal((N, d))
+    fused = ra.Sampler(dm, AdaptScaleHMC(0.6, 3, dm), th0, seed=5)
+    fused.run(T)
+    ph = AdaptScaleHMC(0.6, 3, lambda th: -(P @ (th - mu)), Npars=d)
+    mixed = ra.Sampler(Gauss(), ph, th0, seed=5)
+    mixed.run(T)
+    np.testing.assert_array_equal(mixed._chain_accept, fused._chain_accept)
+    np.testing.assert_allclose(mixed._chain_thetas, fused._chain_thetas, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(ph.scale, fused.proposal.scale, rtol=1e-12)
+    assert np.all(ph.Nsamples == T) and np.std(ph.scale) > 0

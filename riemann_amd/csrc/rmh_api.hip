@@ -984,8 +984,6 @@ int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
                 RwArgs ra{p->d_Ltiles, p->d_V, p->rho};
                 e = launch_propose_rw(p->NT, ra, c, outp, lq, g_stream); // randomwalk.py:89-101
             }
-        } else if (p->kind == kRW && p->acov) {
-            rc = fail(RMH_ERR_PARAM, "propose: stand-alone proposals of an adaptive proposal are not built");
         } else if (p->kind == kRW && p->nblk > 0) {
             rc = fail(RMH_ERR_PARAM, "propose: stand-alone block-mixture proposals are not built");
         } else if (p->kind == kRW && p->NT > 7) {

@@ -114,9 +114,15 @@ class Sampler(object):
                 lxi, logq = DeviceProposal.propose(self.proposal, np.zeros_like(self._th), rng=self._rng)
                 thp = self._th + ada[:, 2:3] * np.atleast_2d(lxi)
                 logq = np.atleast_1d(logq)
+            elif self._mixed_adapt_cov():
+                # AdaptCovRandomWalk next to a Python Model: theta + L xi on the device with the current factor
+                # (as the fused kernel forms it); moments, covariance and factor on the host (below)
+                thp, logq = DeviceProposal.propose(self.proposal, self._th, rng=self._rng)
+                thp, logq = np.atleast_2d(thp), np.atleast_1d(logq)
             elif hasattr(self.proposal, "_pull_adapt") or hasattr(self.proposal, "_init_adapt_cov"):
                 raise TypeError("this adaptive device proposal needs a device Model (next to a Python Model "
-                                "only AdaptScaleRandomWalk is built)")
+                                "AdaptScaleRandomWalk, AdaptCovRandomWalk and AdaptScaleHMC on a Python "
+                                "gradient are built)")
             else:
                 thp, logq = self.proposal.propose(self._th, rng=self._rng)        # :79
                 thp, logq = np.atleast_2d(thp), np.atleast_1d(logq)
@@ -144,7 +150,54 @@ class Sampler(object):
             up = ada[:, 1] / ada[:, 0] > self.proposal.target_accept_rate
             ada[:, 2] = np.where(up, ada[:, 2] * ratio, ada[:, 2] / ratio)
             self._publish_mixed_adapt()
+        elif getattr(self, "_mx_cov", None) is not None and self._mixed_adapt_cov():
+            self._adapt_cov_mixed()
         return ok.astype(np.uint8)
+
+    def _mixed_adapt_cov(self):
+        """AdaptCovRandomWalk (Haario, pooled over the chains) can run next to a Python Model."""
+        from ..proposals.randomwalk import AdaptCovRandomWalk
+        if not isinstance(self.proposal, AdaptCovRandomWalk):
+            return False
+        if getattr(self, "_mx_cov", None) is None:
+            d = self.Npars
+            self._mx_cov = {"n": 0.0, "S": 0.0, "SX": np.zeros(d), "SX2": np.zeros((d, d))}
+        return True
+
+    def _adapt_cov_mixed(self):
+        """AdaptCovProposal.adapt for every chain (adaptive.py:73-102), pooled as the device path pools it
+        (rmh_run_api.hip, acov_update): sums over all chains, update when the per-chain count passes the
+        reference's test, C and L pushed to the device proposal."""
+        p, st, d, th = self.proposal, self._mx_cov, self.Npars, self._th
+        st["n"] += 1.0
+        st["S"] += float(th.shape[0])
+        st["SX"] += th.sum(axis=0)
+        st["SX2"] += th.T @ th
+        n = st["n"]
+        if not n > 2:
+            return
+        r = np.sqrt(n)
+        due = (np.floor(r + 0.5) ** 2 == n) if p.exact_squares else (r * r == n)     # adaptive.py:81-82
+        if not due:
+            return
+        nt, C0 = st["S"], p.C0
+        cs = (st["SX2"] - np.outer(st["SX"], st["SX"]) / nt) / (nt - 1.0)
+        if p.smooth_adapt:
+            cv = (nt * cs + p.t_adapt * C0) / (nt + p.t_adapt)
+        elif nt < p.t_adapt:
+            cv = C0.copy()
+        else:
+            cv = cs + 1e-12 * (np.trace(C0) / d) * np.eye(d)
+        if p.marginalize:
+            cv = np.diag(np.diag(cv))
+        Cn = cv / float(d) ** 0.4
+        try:
+            L = np.linalg.cholesky(Cn) / float(d) ** 0.2                             # adaptive.py:101-102
+        except np.linalg.LinAlgError:
+            raise RuntimeError("AdaptCov: the adapted covariance is not positive definite")
+        p.C, p.L, p._S, p._SX, p._SX2 = Cn, L, n, st["SX"].copy(), st["SX2"].copy()
+        pack = np.concatenate([[n], st["SX"], st["SX2"].ravel(), Cn.ravel(), L.ravel(), [0.0]])
+        _lib.call("rmh_proposal_adapt_cov_set", p._h, _lib.as_f64(pack), float(nt))
 
     def _mixed_adapt_hmc_host(self):
         """AdaptScaleHMC on a Python gradient callable (hamiltonian.py:94-104 with a user's model)."""
@@ -417,6 +470,10 @@ class Sampler(object):
         sampler.py:49-50)."""
         if self._state is None:      # mixed plugins: the chains live on the host
             extra = {"adapt": self._mx_adapt} if getattr(self, "_mx_adapt", None) is not None else {}
+            if getattr(self, "_mx_cov", None) is not None:
+                c = self._mx_cov
+                extra.update(cov_n=c["n"], cov_S=c["S"], cov_SX=c["SX"], cov_SX2=c["SX2"],
+                             cov_C=self.proposal.C, cov_L=self.proposal.L)
             np.savez(path, theta=self._th, logpost=self._lp, rng=self._rng, single=np.bool_(self._single), **extra)
             return
         th, lp = np.empty((self.Nchains, self.Npars)), np.empty(self.Nchains)
@@ -448,6 +505,13 @@ class Sampler(object):
             if "adapt" in z.files:
                 self._mx_adapt = _lib.as_f64(z["adapt"]).copy()
                 self._publish_mixed_adapt()
+            if "cov_n" in z.files and self._mixed_adapt_cov():
+                c, pr = self._mx_cov, self.proposal
+                c["n"], c["S"] = float(z["cov_n"]), float(z["cov_S"])
+                c["SX"], c["SX2"] = _lib.as_f64(z["cov_SX"]).copy(), _lib.as_f64(z["cov_SX2"]).copy()
+                pr.C, pr.L = _lib.as_f64(z["cov_C"]).copy(), _lib.as_f64(z["cov_L"]).copy()
+                pack = np.concatenate([[c["n"]], c["SX"], c["SX2"].ravel(), pr.C.ravel(), pr.L.ravel(), [0.0]])
+                _lib.call("rmh_proposal_adapt_cov_set", pr._h, _lib.as_f64(pack), c["S"])
             self._host_thetas, self._host_logpost = self._th[None].copy(), self._lp[None].copy()
             self._host_accept = np.zeros((0, self.Nchains), dtype=np.uint8)
             self._kept = 1

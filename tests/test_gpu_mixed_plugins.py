@@ -141,7 +141,7 @@ def test_python_model_with_device_adaptive_scale_random_walk(ra, tmp_path):
     the kernel from the device library), adapted scales included; checkpoint / restore carries the
     adaptation state.  The other adaptive device proposals still need a device Model."""
     from riemann_amd.models import MultiGaussianDist
-    from riemann_amd.proposals import AdaptCovRandomWalk, AdaptScaleRandomWalk
+    from riemann_amd.proposals import AdaptScaleRandomWalk
     g = np.random.default_rng(5)
     d, N, T = 6, 40, 120
     A = g.standard_normal((d, d))
@@ -175,7 +175,8 @@ def test_python_model_with_device_adaptive_scale_random_walk(ra, tmp_path):
     again.run(T - 70)
     np.testing.assert_array_equal(again._chain_thetas, mixed._chain_thetas)
     np.testing.assert_array_equal(again.proposal.scale, pm.scale)
-    s = ra.Sampler(Gauss(), AdaptCovRandomWalk(np.eye(d)), np.zeros(d), seed=1)
+    from riemann_amd.proposals import AdaptScalepCN
+    s = ra.Sampler(Gauss(), AdaptScalepCN(np.eye(d), 0.9), np.zeros(d), seed=1)
     with pytest.raises(TypeError):
         s.run(2)
 
@@ -242,3 +243,47 @@ def test_adaptive_scale_hmc_on_a_python_gradient(ra):
     np.testing.assert_allclose(mixed._chain_thetas, fused._chain_thetas, rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(ph.scale, fused.proposal.scale, rtol=1e-12)
     assert np.all(ph.Nsamples == T) and np.std(ph.scale) > 0
+
+
+@pytest.mark.parametrize("smooth,squares", [(True, False), (False, True)])
+def test_python_model_with_device_adaptive_covariance_random_walk(ra, tmp_path, smooth, squares):
+    """AdaptCovRandomWalk (Haario) next to a user's numpy Model -- the reference's everyday combination:
+    theta + L xi on the device with the current factor, moments / covariance / Cholesky factor on the host
+    as adaptive.py:73-102 computes them (pooled over the chains as the fused path pools them).  Same
+    chains as the fused device run to rounding (numpy's sums and LAPACK's factor against the kernels'),
+    adapted C and L included; checkpoint / restore carries the adaptation."""
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import AdaptCovRandomWalk
+    g = np.random.default_rng(17)
+    d, N, T = 4, 32, 90
+    A = g.standard_normal((d, d))
+    Cov, mu = A @ A.T + d * np.eye(d), g.standard_normal(d)
+    Li = np.linalg.inv(np.linalg.cholesky(Cov))
+    logdet = np.log(np.linalg.det(Cov))
+
+    class Gauss(ra.Model):
+        def log_prior(self, theta):
+            return 0.0
+
+        def log_likelihood(self, theta):
+            u = Li @ (theta - mu)
+            return -0.5 * (u @ u + logdet + d * np.log(2 * np.pi))
+
+    kw = dict(t_adapt=200, smooth_adapt=smooth, exact_squares=squares)
+    th0 = mu + g.standard_normal((N, d))
+    fused = ra.Sampler(MultiGaussianDist(mu, Cov), AdaptCovRandomWalk(0.5 * np.eye(d), **kw), th0, seed=6)
+    fused.run(T)
+    pm = AdaptCovRandomWalk(0.5 * np.eye(d), **kw)
+    mixed = ra.Sampler(Gauss(), pm, th0, seed=6)
+    mixed.run(50)
+    mixed.checkpoint(str(tmp_path / "cov.npz"))
+    mixed.run(T - 50)
+    np.testing.assert_array_equal(mixed._chain_accept, fused._chain_accept[50:])
+    np.testing.assert_allclose(mixed._chain_thetas, fused._chain_thetas[50:], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(pm.C, fused.proposal.C, rtol=1e-9)
+    np.testing.assert_allclose(pm.L, fused.proposal.L, rtol=1e-9, atol=1e-12)
+    assert not np.allclose(pm.C, 0.5 * np.eye(d) / d ** 0.4)          # it did adapt
+    again = ra.Sampler(Gauss(), AdaptCovRandomWalk(0.5 * np.eye(d), **kw), th0, seed=6)
+    again.restore(str(tmp_path / "cov.npz"))
+    again.run(T - 50)
+    np.testing.assert_array_equal(again._chain_thetas, mixed._chain_thetas)

@@ -4,9 +4,11 @@ samples (riemann/samplers/sampler.py:72-90, proposals/hamiltonian.py:60-70).
 
 1. a user's numpy Model sampled by the device MetropolisRandomWalk;
 2. the same Model with VanillaHMC on its own Python gradient (host leapfrog, device-drawn momenta);
-3. a user's Proposal on a device Model;
-4. for comparison, the all-device version of (2): one fused launch.
-In 1-3 the Sampler runs the reference's loop on the host with the chains' device stream, so chain
+3. the same Model with the adaptive proposals it is usually paired with: AdaptCovRandomWalk (Haario; moments
+   and Cholesky factor on the host, theta + L xi on the device) and AdaptScaleHMC on the Python gradient;
+4. a user's Proposal on a device Model;
+5. for comparison, the all-device version of (2): one fused launch.
+In 1-4 the Sampler runs the reference's loop on the host with the chains' device stream, so chain
 c sees the same random numbers as in the fused path."""
 import os
 import sys
@@ -18,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import riemann_amd as ra                                              # noqa: E402
 from riemann_amd.models import LogisticRegression                     # noqa: E402
-from riemann_amd.proposals import MetropolisRandomWalk, VanillaHMC    # noqa: E402
+from riemann_amd.proposals import AdaptCovRandomWalk, AdaptScaleHMC, MetropolisRandomWalk, VanillaHMC    # noqa: E402
 from riemann_amd.workloads import logreg_data                         # noqa: E402
 
 
@@ -56,6 +58,9 @@ def main(nchains=64, T=200):
     th0 = np.zeros((nchains, 8))
     runs = [("numpy Model + device random walk", user, MetropolisRandomWalk(0.02 * np.eye(8))),
             ("numpy Model + HMC on its Python gradient", user, VanillaHMC(0.15, 5, user.grad_log_posterior, Npars=8)),
+            ("numpy Model + device AdaptCovRandomWalk", user, AdaptCovRandomWalk(0.02 * np.eye(8), t_adapt=500,
+                                                                                    smooth_adapt=True)),
+            ("numpy Model + AdaptScaleHMC on its gradient", user, AdaptScaleHMC(0.15, 5, user.grad_log_posterior, Npars=8)),
             ("device Model + user's Proposal", dev, MyWalk(0.12, 3)),
             ("device Model + device HMC (fused)", dev, VanillaHMC(0.15, 5, dev))]
     for name, m, p in runs:

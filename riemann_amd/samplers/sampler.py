@@ -121,8 +121,8 @@ class Sampler(object):
                 thp, logq = np.atleast_2d(thp), np.atleast_1d(logq)
             elif hasattr(self.proposal, "_pull_adapt") or hasattr(self.proposal, "_init_adapt_cov"):
                 raise TypeError("this adaptive device proposal needs a device Model (next to a Python Model "
-                                "AdaptScaleRandomWalk, AdaptCovRandomWalk and AdaptScaleHMC on a Python "
-                                "gradient are built)")
+                                "AdaptScaleRandomWalk, AdaptCovRandomWalk, AdaptScaleCovRandomWalk and "
+                                "AdaptScaleHMC on a Python gradient are built)")
             else:
                 thp, logq = self.proposal.propose(self._th, rng=self._rng)        # :79
                 thp, logq = np.atleast_2d(thp), np.atleast_1d(logq)
@@ -150,14 +150,16 @@ class Sampler(object):
             up = ada[:, 1] / ada[:, 0] > self.proposal.target_accept_rate
             ada[:, 2] = np.where(up, ada[:, 2] * ratio, ada[:, 2] / ratio)
             self._publish_mixed_adapt()
-        elif getattr(self, "_mx_cov", None) is not None and self._mixed_adapt_cov():
+            if self._mixed_adapt_cov():          # AdaptScaleCovRandomWalk: scale per chain AND pooled covariance
+                self._adapt_cov_mixed()
+        elif self._mixed_adapt_cov():
             self._adapt_cov_mixed()
         return ok.astype(np.uint8)
 
     def _mixed_adapt_cov(self):
         """AdaptCovRandomWalk (Haario, pooled over the chains) can run next to a Python Model."""
-        from ..proposals.randomwalk import AdaptCovRandomWalk
-        if not isinstance(self.proposal, AdaptCovRandomWalk):
+        from ..proposals.randomwalk import AdaptCovRandomWalk, AdaptScaleCovRandomWalk
+        if not isinstance(self.proposal, (AdaptCovRandomWalk, AdaptScaleCovRandomWalk)):
             return False
         if getattr(self, "_mx_cov", None) is None:
             d = self.Npars
@@ -213,8 +215,8 @@ class Sampler(object):
 
     def _mixed_adapt_scale(self):
         """AdaptScaleRandomWalk can run next to a Python Model (the other adaptive device proposals cannot)."""
-        from ..proposals.randomwalk import AdaptScaleRandomWalk
-        if not isinstance(self.proposal, AdaptScaleRandomWalk):
+        from ..proposals.randomwalk import AdaptScaleCovRandomWalk, AdaptScaleRandomWalk
+        if not isinstance(self.proposal, (AdaptScaleRandomWalk, AdaptScaleCovRandomWalk)):
             return False
         if getattr(self, "_mx_adapt", None) is None:
             a = np.zeros((self.Nchains, 3))

@@ -245,15 +245,16 @@ def test_adaptive_scale_hmc_on_a_python_gradient(ra):
     assert np.all(ph.Nsamples == T) and np.std(ph.scale) > 0
 
 
-@pytest.mark.parametrize("smooth,squares", [(True, False), (False, True)])
-def test_python_model_with_device_adaptive_covariance_random_walk(ra, tmp_path, smooth, squares):
+@pytest.mark.parametrize("smooth,squares,scaled", [(True, False, False), (False, True, False), (True, False, True)])
+def test_python_model_with_device_adaptive_covariance_random_walk(ra, tmp_path, smooth, squares, scaled):
     """AdaptCovRandomWalk (Haario) next to a user's numpy Model -- the reference's everyday combination:
     theta + L xi on the device with the current factor, moments / covariance / Cholesky factor on the host
     as adaptive.py:73-102 computes them (pooled over the chains as the fused path pools them).  Same
     chains as the fused device run to rounding (numpy's sums and LAPACK's factor against the kernels'),
     adapted C and L included; checkpoint / restore carries the adaptation."""
     from riemann_amd.models import MultiGaussianDist
-    from riemann_amd.proposals import AdaptCovRandomWalk
+    from riemann_amd import proposals as P
+    AdaptCovRandomWalk = P.AdaptScaleCovRandomWalk if scaled else P.AdaptCovRandomWalk   # scaled: + per-chain scale
     g = np.random.default_rng(17)
     d, N, T = 4, 32, 90
     A = g.standard_normal((d, d))
@@ -283,6 +284,8 @@ def test_python_model_with_device_adaptive_covariance_random_walk(ra, tmp_path, 
     np.testing.assert_allclose(pm.C, fused.proposal.C, rtol=1e-9)
     np.testing.assert_allclose(pm.L, fused.proposal.L, rtol=1e-9, atol=1e-12)
     assert not np.allclose(pm.C, 0.5 * np.eye(d) / d ** 0.4)          # it did adapt
+    if scaled:
+        np.testing.assert_allclose(pm.scale, fused.proposal.scale, rtol=1e-12)
     again = ra.Sampler(Gauss(), AdaptCovRandomWalk(0.5 * np.eye(d), **kw), th0, seed=6)
     again.restore(str(tmp_path / "cov.npz"))
     again.run(T - 50)

@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainAr
         double ua[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) ua[b] = u01(xo_next_if(st[b], g == 0));   // the accept word: sub-stream 0
-        constexpr int PL = 1;                     // passes evaluated in lockstep
+        constexpr int PL = 2;                     // passes evaluated in lockstep
 #pragma unroll
         for (int b0 = 0; b0 < 4; b0 += PL) {
             uint32_t h[PL * NS];

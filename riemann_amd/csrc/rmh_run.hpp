@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         asm volatile("" ::: "memory");
         if (PT) pt.select(run, rng, cl);
         double xi[S];
-        T::template normals_fixed<13, 100>(rng, ch.d, g, tab, xi);   // d = 97..100: 13 words
+        T::template normals_fixed<13, 100, 3>(rng, ch.d, g, tab, xi);   // d = 97..100: 13 words
         // theta' = theta + scale * L xi: row tiles 0..5 on the matrix core, rows 96..99 on the VALU
         // (ADAPT: the chain's own scale times the unscaled image's product, as in k_run_rw)
         double4_t acc[NF];

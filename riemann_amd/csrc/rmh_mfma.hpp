@@ -215,7 +215,8 @@ struct Tile {
     // coefficients (105 scratch round trips per iteration, 210 ms); an opaque always-taken scalar
     // branch costs two SALU instructions.  Normals per block, cfg2: 1 (evaluated one after the
     // other) 32.6 ms, 2 in lockstep 32.0 ms, 4 in lockstep 31.8 ms (44 coefficient registers per
-    // normal pair: kernels at four waves per SIMD take WPB = 1).
+    // normal pair: kernels at four waves per SIMD take WPB = 1).  With the v4 stream (14 coefficient
+    // registers per normal) the cfg2 kernel takes WPB = 3, six normals per block; eight spill.
     template <int MW, int DMAX, int WPB, int M0>
     static RMH_DEV void fixed_block(Xo &rng, int d, int g, const double *tab, double (&xi)[S])
     {

@@ -284,6 +284,20 @@ int rmh_debug_rng_stream(uint64_t seed, uint64_t chain0, int64_t N, int d, int T
 /* D = A(16x4) B(4x16) + C(16x16) through one v_mfma_f64_16x16x4_f64, row-major in/out */
 int rmh_debug_mfma(const double *A, const double *B, const double *C, double *D);
 
+/* Kernel selection for A/B measurements and cross-checks (tests, tools/): a bit mask that
+ * turns specialised kernels off or forces them.  Not part of the reference's interface; the
+ * library never reads the environment for this.  Returns the previous mask through *old
+ * (may be null).  Default 0 = the library picks. */
+#define RMH_POLICY_NO_TAIL        0x01  /* d = 16 q + 1..4: generic padded row tile instead of the VALU tail rows */
+#define RMH_POLICY_CP_NO_SS       0x02  /* changepoint: O(n) likelihood loop instead of sufficient statistics */
+#define RMH_POLICY_CP_SS64        0x04  /* changepoint: one-lane-per-chain kernels at any chain count */
+#define RMH_POLICY_CP_SS16        0x08  /* changepoint: four-lanes-per-chain kernels at any chain count */
+#define RMH_POLICY_CP_NO_BUCKETS  0x10  /* changepoint: plain binary searches, no bucket table */
+#define RMH_POLICY_CPRJ_NO_SS     0x20  /* trans-dimensional changepoint: O(n k) likelihood loop */
+#define RMH_POLICY_ACOV_HOST      0x40  /* AdaptCov: covariance update on the host */
+#define RMH_POLICY_ACOV_UNFUSED   0x80  /* AdaptCov: scratch history + k_moments instead of in-kernel moments */
+int rmh_debug_set_kernel_policy(int mask, int *old);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,7 @@ SIGNATURES = {
     "rmh_allreduce_moments": [_vp, _f64],
     "rmh_debug_rng_stream": [_u64s, _u64s, _i64, _int, _int, _f64, _f64],
     "rmh_debug_mfma": [_f64, _f64, _f64, _f64],
+    "rmh_debug_set_kernel_policy": [_int, C.POINTER(_int)],
 }
 
 _lib = None
@@ -136,47 +137,82 @@ def as_f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+# ---- kernel policy (A/B measurements, cross-checks) ---------------------------------------------
+POLICY = {"NO_TAIL": 0x01, "CP_NO_SS": 0x02, "CP_SS64": 0x04, "CP_SS16": 0x08, "CP_NO_BUCKETS": 0x10,
+          "CPRJ_NO_SS": 0x20, "ACOV_HOST": 0x40, "ACOV_UNFUSED": 0x80}
+
+
+class kernel_policy(object):
+    """``with kernel_policy("CP_SS64", "CP_NO_BUCKETS"): ...`` -- rmh_debug_set_kernel_policy for the
+    block (include/riemann_hip.h, RMH_POLICY_*).  The library reads no environment variable."""
+
+    def __init__(self, *names):
+        self.mask = 0
+        for n in names:
+            self.mask |= POLICY[n]
+
+    def __enter__(self):
+        old = _int()
+        call("rmh_debug_set_kernel_policy", self.mask, C.byref(old))
+        self.old = old.value
+        return self
+
+    def __exit__(self, *exc):
+        call("rmh_debug_set_kernel_policy", self.old, None)
+        return False
+
+
 # ---- pinned host arrays (history downloads at the PCIe rate, rmh_host_alloc) --------------------
-class PinnedPool(object):
-    """Page-locked numpy arrays for one owner (a Sampler's history downloads).  Pinning costs about
-    as much as a pageable transfer, so buffers are kept and handed out again -- but only when no
-    array created from them is referenced any more (the user may still hold the previous run's
-    history), checked through the buffer object's reference count."""
+class _PinnedAlloc(object):
+    """One page-locked allocation; freed when the pool and every lease of it are gone."""
 
-    def __init__(self, max_bytes=None):
-        self.max_bytes = int(os.environ.get("RMH_PINNED_MAX_BYTES", 16 << 30)) if max_bytes is None else max_bytes
-        self._bufs = []
-
-    def _alloc(self, nbytes):
+    def __init__(self, nbytes):
         p = C.c_void_p()
         call("rmh_host_alloc", C.byref(p), nbytes)
-        addr = p.value
+        self.addr, self.nbytes, self.busy = p.value, nbytes, False
 
-        def _free(self_buf, addr=addr):
-            try:
-                load().rmh_host_free(addr)
-            except Exception:
-                pass
-        cls = type("PinnedBuffer", (C.c_char * nbytes,), {"__del__": _free})
-        return cls.from_address(addr)
+    def release(self):
+        self.busy = False
+
+    def __del__(self):
+        try:
+            load().rmh_host_free(self.addr)
+        except Exception:
+            pass
+
+
+class PinnedPool(object):
+    """Page-locked numpy arrays for one owner (a Sampler's history downloads).  Pinning costs about
+    as much as a pageable transfer, so allocations are kept and handed out again -- but only when
+    no array made from the previous hand-out is alive any more (the user may still hold the
+    previous run's history).  Liveness is explicit: every hand-out wraps the allocation in a fresh
+    lease object that is the ``base`` of the array and of all its views; a ``weakref.finalize`` on
+    the lease marks the allocation free."""
+
+    def __init__(self, max_bytes=None):
+        self.max_bytes = int(os.environ.get("RMH_PINNED_MAX_BYTES", 4 << 30)) if max_bytes is None else max_bytes
+        self._allocs = []
 
     def empty(self, shape, dtype=np.float64):
         """A pinned array of the shape, or a pageable one when the pool's budget does not allow it."""
-        import sys
+        import weakref
         n = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
         if n == 0 or n > self.max_bytes:
             return np.empty(shape, dtype=dtype)
         pick = None
-        for b in self._bufs:      # free = referenced by the list, the loop variable and getrefcount only
-            if len(b) >= n and sys.getrefcount(b) <= 3 and (pick is None or len(b) < len(pick)):
-                pick = b
+        for a in self._allocs:
+            if a.nbytes >= n and not a.busy and (pick is None or a.nbytes < pick.nbytes):
+                pick = a
         if pick is None:
-            self._bufs = [b for b in self._bufs if sys.getrefcount(b) > 3]     # drop idle smaller ones
-            if sum(len(b) for b in self._bufs) + n > self.max_bytes:
+            self._allocs = [a for a in self._allocs if a.busy]     # drop idle smaller ones
+            if sum(a.nbytes for a in self._allocs) + n > self.max_bytes:
                 return np.empty(shape, dtype=dtype)
             try:
-                pick = self._alloc(n)
+                pick = _PinnedAlloc(n)
             except RuntimeError:
                 return np.empty(shape, dtype=dtype)
-            self._bufs.append(pick)
-        return np.frombuffer(pick, dtype=dtype, count=n // np.dtype(dtype).itemsize).reshape(shape)
+            self._allocs.append(pick)
+        lease = type("PinnedLease", (C.c_char * n,), {}).from_address(pick.addr)
+        pick.busy = True
+        weakref.finalize(lease, pick.release)      # (the bound method keeps the allocation alive)
+        return np.frombuffer(lease, dtype=dtype, count=n // np.dtype(dtype).itemsize).reshape(shape)

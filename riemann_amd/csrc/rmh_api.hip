@@ -12,6 +12,7 @@ using namespace rmh;
 using namespace rmh::host;
 
 namespace rmh {
+int g_kernel_policy = 0;   // rmh_debug_set_kernel_policy
 namespace host {
 
 // ------------------------------------------------------------------ context
@@ -1465,6 +1466,13 @@ int rmh_debug_rng_stream(uint64_t seed, uint64_t chain0, int64_t N, int d, int T
     if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
     (void)hipFree(rng); (void)hipFree(dxi); (void)hipFree(du);
     RMH_HIP(e);
+    return RMH_OK;
+}
+
+int rmh_debug_set_kernel_policy(int mask, int *old)
+{
+    if (old) *old = rmh::g_kernel_policy;
+    rmh::g_kernel_policy = mask;
     return RMH_OK;
 }
 

@@ -57,6 +57,7 @@ struct rmh_proposal {
     int acov_NT = 0;                            // tiles of the (d+1)-row moment matrix
     std::vector<double> acov_C0, acov_C;        // initial and current covariance (host)
     double *d_acov_acc = nullptr, *d_acov_partial = nullptr; // moment sums, per-workgroup partials
+    size_t acov_partial_cap = 0;                             // doubles allocated behind d_acov_partial
     // device-side update (random-walk variant): C0, the current C and L, a scratch copy of the
     // sums for the all-reduce, the not-positive-definite flag; the host copies acov_C / L are
     // refreshed on demand (acov_host_stale)

@@ -1,6 +1,7 @@
 // rmh_internal.hpp -- structures shared by the kernel files and the C-ABI layer.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "../../include/riemann_hip.h"   // RMH_POLICY_*
 #include <stdint.h>
 #include <vector>
 
@@ -8,6 +9,11 @@ namespace rmh {
 
 enum ModelKind { kGauss = 1, kLogReg = 2, kChangepoint = 3, kMixture = 4, kChangepointRJ = 5 };
 enum ProposalKind { kRW = 1, kHMC = 2, kPCN = 3, kCpRJ = 4 };
+
+// rmh_debug_set_kernel_policy (include/riemann_hip.h, RMH_POLICY_*): tests and tools switch
+// specialised kernels off or on through it; the launch path reads no environment variable
+extern int g_kernel_policy;
+inline bool policy(int bit) { return (g_kernel_policy & bit) != 0; }
 
 // ---- device-side argument blocks (passed by value to the kernels) ----------
 struct GaussArgs {
@@ -108,6 +114,12 @@ struct RunArgs {
     const double *pt_beta; // (ld) inverse temperature of every slot
     int pt_K;              // ladder size: a 16-slot tile holds 16/K ensembles, rung-minor
     double pt_pswap;
+    // pooled second moments accumulated inside the sampling kernel (AdaptCov, MomFused in
+    // rmh_run.hpp): per-workgroup partial sums of z z^T, z = (theta, 1), over the states 1..T of
+    // the launch, NTRI x 256 doubles per workgroup in the tile-pair layout of k_moments; chains
+    // >= mom_N (padding) do not count.  Null: off.
+    double *mom_partial;
+    int64_t mom_N;
 };
 
 struct RwArgs {
@@ -158,6 +170,9 @@ hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const Ch
                            const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_gauss_rw_tail(const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                                 const RunArgs &r, bool adapt, hipStream_t st);
+// workgroups of launch_gauss_rw_tail for `nblocks` 16-chain blocks (= partial sums written
+// when r.mom_partial is set)
+int64_t gauss_rw_tail_workgroups(int64_t nblocks);
 hipError_t launch_gauss_pt(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                            const RunArgs &r, hipStream_t st);
 hipError_t launch_mix_eval(int NT, const MixArgs &m, const ChainArgs &c, int want_grad, double *lp_out,
@@ -219,6 +234,8 @@ hipError_t launch_acov_update(const AcovUpdateArgs &a, hipStream_t st);
 // pooled second moments of history entries [e0, e1): see rmh_kernels_mfma.hip
 hipError_t launch_moments(int NT, const double *hist, int64_t e0, int64_t e1, int rows, int64_t ld,
                           int64_t N, int d, double *partial, int nwg, double *acc, hipStream_t st);
+// acc[x] += sum over the nwg per-workgroup partials (n doubles each), in a fixed order
+hipError_t launch_moments_reduce(const double *partial, int64_t nwg, int n, double *acc, hipStream_t st);
 hipError_t launch_big_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                                const RunArgs &r, hipStream_t st);
 hipError_t launch_big_gauss_eval(int NT, const GaussArgs &m, const ChainArgs &c, double *lp_out,

@@ -15,7 +15,6 @@
 // per recorded sample), instruction-issue bound in practice.
 #include "rmh_run.hpp"
 
-#include <cstdlib>
 
 namespace rmh {
 
@@ -764,10 +763,10 @@ static hipError_t cp_rw_ss_launch(const CpArgs &m, const RwArgs &p, const ChainA
     // one lane per chain (k_cp_rw_ss64: 4 waves x 64 chains per workgroup) once there are enough
     // chains to give every SIMD of the chip a wavefront of 64 (65 536: one each); below that the
     // four-lanes-per-chain kernel keeps four times as many waves in flight
-    if (p.nblk == 0 && (getenv("RMH_CP_SS64") || (c.nblocks >= 4096 && !getenv("RMH_CP_SS16")))) {
+    if (p.nblk == 0 && (policy(RMH_POLICY_CP_SS64) || (c.nblocks >= 4096 && !policy(RMH_POLICY_CP_SS16)))) {
         constexpr int DE = 2 * ((D + 2) / 2), TS64 = 2 * ((DE / 2) | 1);
         const int nw = 4;
-        const bool buckets = m.ss_nb > 0 && !getenv("RMH_CP_NO_BUCKETS");
+        const bool buckets = m.ss_nb > 0 && !policy(RMH_POLICY_CP_NO_BUCKETS);
         const size_t bkd = buckets ? (size_t)(((m.ss_nb + 2) / 2 + 1) & ~1) : 0;
         const size_t lds = sizeof(double) * ((size_t)2 * np + 2 + bkd + kIcdfDoubles + (size_t)nw * 64 * TS64);
         if (lds <= 160 * 1024) {
@@ -1250,9 +1249,9 @@ __global__ void __launch_bounds__(256) k_cprj_eval(CpRjArgs m, ChainArgs ch, dou
 
 hipError_t launch_cprj_run(const CpRjArgs &m, const ChainArgs &c, const RunArgs &r, hipStream_t st)
 {
-    // likelihood from sufficient statistics when the model has them (n <= 2047); RMH_CPRJ_NO_SS
+    // likelihood from sufficient statistics when the model has them (n <= 2047); RMH_POLICY_CPRJ_NO_SS
     // keeps the O(n k) loop over the data (measurements, cross-checks)
-    const bool ss = m.base.ss_xp && !getenv("RMH_CPRJ_NO_SS");
+    const bool ss = m.base.ss_xp && !policy(RMH_POLICY_CPRJ_NO_SS);
     const int np = (1 << m.base.ss_steps) - 1;
     const size_t ndata = ss ? (size_t)2 * np + 2 : (size_t)2 * m.base.n;
     const size_t lds = sizeof(double) * (ndata + 4 * (m.KM + 2) + kIcdfDoubles + 4 * 16 * 32 +

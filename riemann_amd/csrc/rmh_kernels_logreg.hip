@@ -3,7 +3,6 @@
 #include "rmh_run.hpp"
 #include "rmh_launch.hpp"
 
-#include <cstdlib>
 
 namespace rmh {
 
@@ -63,7 +62,7 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
         // although the 256-register cap costs ~300 spilled registers outside the loop.
         constexpr int NW = (kNT >= 5) ? 8 : 4;
         if constexpr (kNT == 7) { // d = 97..100: columns 96..99 of the gradient on the VALU (rmh_models.hpp)
-            if (m.ks == 25 && r.pt_K == 0 && !p.chM && !getenv("RMH_NO_TAIL")) {
+            if (m.ks == 25 && r.pt_K == 0 && !p.chM && !policy(RMH_POLICY_NO_TAIL)) {
                 using MT = LogRegModel<7, true>;
                 if (adapt) return launch(k_run_hmc<MT, NW, true, false>, c.nblocks, NW, lds, st, m, p, c, r);
                 return launch(k_run_hmc<MT, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);

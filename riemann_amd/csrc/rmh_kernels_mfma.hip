@@ -45,10 +45,17 @@ hipError_t launch_gauss_rw_tail(const GaussArgs &m, const RwArgs &p, const Chain
                                 const RunArgs &r, bool adapt, hipStream_t st)
 {
     const size_t lds = sizeof(double) * (2 * tri_tiles(6) * 64 + 2 * kTailDoubles + 4 * 28 + kIcdfDoubles);
+    if (r.mom_partial) { // AdaptCov: the pooled moments of the states 1..T accumulated in the kernel
+        if (r.pt_K > 0 || adapt) return hipErrorInvalidValue;
+        return launch(k_run_rw_tail<8, false, false, true>, c.nblocks, 8, lds + sizeof(double) * 2 * kMomPanel, st,
+                      m, p, c, r);
+    }
     if (r.pt_K > 0) return launch(k_run_rw_tail<8, false, true>, c.nblocks, 8, lds, st, m, p, c, r);
     if (adapt) return launch(k_run_rw_tail<8, true, false>, c.nblocks, 8, lds, st, m, p, c, r);
     return launch(k_run_rw_tail<8, false, false>, c.nblocks, 8, lds, st, m, p, c, r);
 }
+
+int64_t gauss_rw_tail_workgroups(int64_t nblocks) { return (nblocks + 7) / 8; }
 
 // parallel tempering over a Gaussian target: one wave per SIMD (register budget)
 hipError_t launch_gauss_pt(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
@@ -189,14 +196,14 @@ __global__ void __launch_bounds__(256) k_moments(const double *hist, int64_t e0,
 
 // acc[x] += sum_g partial[g][x], g in a fixed order: 16 threads per output each add a
 // strided sixteenth of the partials, then thread 0 of the group adds the 16 in order
-__global__ void __launch_bounds__(256) k_moments_reduce(const double *partial, int nwg, int n, double *acc)
+__global__ void __launch_bounds__(256) k_moments_reduce(const double *partial, int64_t nwg, int n, double *acc)
 {
     __shared__ double part[16][17];
     const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int x = blockIdx.x * 16 + o;
     double s = 0.0;
     if (x < n)
-        for (int g = grp; g < nwg; g += 16) s += partial[(int64_t)g * n + x];
+        for (int64_t g = grp; g < nwg; g += 16) s += partial[g * n + x];
     part[o][grp] = s;
     __syncthreads();
     if (grp == 0 && x < n) {
@@ -204,6 +211,12 @@ __global__ void __launch_bounds__(256) k_moments_reduce(const double *partial, i
         for (int g = 0; g < 16; ++g) t += part[o][g];
         acc[x] = t;
     }
+}
+
+hipError_t launch_moments_reduce(const double *partial, int64_t nwg, int n, double *acc, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_moments_reduce, dim3((n + 15) / 16), dim3(256), 0, st, partial, nwg, n, acc);
+    return hipGetLastError();
 }
 
 // acc (NTRI*256 doubles, tile-pair order) += moments of hist entries [e0, e1)
@@ -217,8 +230,7 @@ hipError_t launch_moments(int NT, const double *hist, int64_t e0, int64_t e1, in
         hipError_t e = launch(k_moments<kNT>, (int64_t)nwg * 4, 4, lds, st, hist, e0, e1, rows, ld, N, d, partial);
         if (e != hipSuccess) return e;
         const int n = NTRI * 256;
-        hipLaunchKernelGGL(k_moments_reduce, dim3((n + 15) / 16), dim3(256), 0, st, partial, nwg, n, acc);
-        return hipGetLastError();
+        return launch_moments_reduce(partial, nwg, n, acc, st);
     })
 }
 
@@ -259,10 +271,16 @@ RMH_DEV double mom_at(const double *acc, int row, int col)
 // that one lost to a host round trip: 212 vs 175 ms per 1000 iterations at the cfg2 size).  Every
 // element still receives its subtractions for k = 0, 1, 2, ... in that order, one multiply and
 // one subtract each, as the host loop (rmh_run_api.hip, cholesky_lower) does: same bits.
+// Row stride of the LDS matrix: odd.  (Round 3 tried an even stride = 2 (mod 4) so that every row
+// starts 16-byte aligned for the compiler's ds_read_b128 / ds_read2_b64 of consecutive k: the
+// update went from 68 to ~140 us -- the one-thread-per-row phases read a column of 32..64 rows per
+// instruction, and an even stride folds those onto a quarter of the banks.)
+__host__ __device__ constexpr int acov_row_stride(int d) { return d | 1; }
+
 __global__ void __launch_bounds__(1024) k_acov_update(AcovUpdateArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double A[]; // d x ds, row-major
-    const int d = a.d, ds = d | 1, tid = threadIdx.x, nth = blockDim.x;
+    const int d = a.d, ds = acov_row_stride(d), tid = threadIdx.x, nth = blockDim.x;
     const double ntot = mom_at(a.acc, d, d);
     const double creg = a.creg;                                  // 1e-12 * mean(diag C0), adaptive.py:95-96
     for (int idx = tid; idx < d * d; idx += nth) {
@@ -307,7 +325,7 @@ __global__ void __launch_bounds__(1024) k_acov_update(AcovUpdateArgs a)
 #pragma unroll
                 for (int k = 0; k < c; ++k) t -= x[k] * readlane_f64(x[k], c); // A[r][k] * A[c][k]
                 const double piv = readlane_f64(t, c);
-                if (c < pw && !(piv > 0.0)) *a.status = 1;
+                if (c < pw && !(piv > 0.0) && RMH_MOM_ABL == 0) *a.status = 1;
                 const double ljj = sqrt(piv);
                 x[c] = (r == c) ? ljj : t / ljj;                 // rows above the diagonal: unused
             }
@@ -370,7 +388,7 @@ __global__ void __launch_bounds__(1024) k_acov_update(AcovUpdateArgs a)
 
 hipError_t launch_acov_update(const AcovUpdateArgs &a, hipStream_t st)
 {
-    const size_t lds = sizeof(double) * (size_t)a.d * (a.d | 1);
+    const size_t lds = sizeof(double) * (size_t)a.d * acov_row_stride(a.d);
     return launch(k_acov_update, 16, 16, lds, st, a); // one workgroup of 1024 threads
 }
 

@@ -375,7 +375,273 @@ RMH_DEV double gauss_loglik(const double *Wimg, const double *Wt, const GaussArg
     return -0.5 * ((uu + m.dlog2pi) + m.logdetC);
 }
 
-template <int NW, bool ADAPT = false, bool PT = false>
+// ---- pooled second moments inside the sampling kernel (AdaptCov) --------------------------
+// AdaptCovProposal.adapt (riemann/proposals/adaptive.py:73-76) adds theta and theta theta^T of
+// the chain's state after EVERY step; pooled over the chains that is S += sum_c z_c z_c^T with
+// z = (theta, 1), a (d+1) x (d+1) symmetric product per iteration.  Round 2 wrote every state
+// of a stretch to a scratch history and re-read it in k_moments (2 x 53 GB per 1000 iterations
+// at the cfg2 size, two more launches per update).  Here the workgroup forms the product
+// itself, right after the accept step, from the states its eight wavefronts hold in registers:
+//  * a state tile is (parameter 4s+g, chain cl) per lane; the matrix core wants the CHAIN as the
+//    contraction index -- lane (m, k) <- z[16i + m][chain 4q + k] for both operands -- so every
+//    wavefront passes its 16 chains through a small LDS panel (112 rows, stride 17 doubles:
+//    conflict-free for ds_read_b64 up to one bank pair, and for the ds_read2_b64 the compiler may
+//    merge two gathers into -- banked modulo 32 dwords over 16-lane groups -- where an even
+//    stride is 2-way);
+//  * the 28 lower tile pairs of the 7 x 7 tile grid are dealt to the eight wavefronts as 2 x 2
+//    blocks {row tiles X2, X3} x {column tiles X0, X1}: four operand reads for four MFMAs per
+//    k-block and ONE code path for all wavefronts (kMomTiles below; a first version with two MFMA
+//    patterns behind a wave-uniform branch made the compiler copy all accumulators between the two
+//    register assignments every round, draining the matrix pipe each time);
+//  * 16 accumulator doubles per lane, kept in this workgroup's slice of run.mom_partial between
+//    iterations (L2 resident; the sampling code is at the 256-register cap and would spill them
+//    to scratch anyway), read back before the accept step;
+//  * eight rounds per iteration, round k = the chains of wavefront k, software-pipelined: after
+//    the barrier that publishes panel k+1 every wavefront interleaves ITS reads of panel k+1 with
+//    the MFMAs of round k (operands in registers since the previous round) -- eight reads, four
+//    MFMAs, eight reads ...: issued up front, the reads of eight wavefronts fill the LDS queue and
+//    hold the matrix pipe back -- and wavefront k+2 refills panel k's buffer in the middle of the
+//    round.  ONE workgroup barrier per round, and it waits for LDS traffic only (lds_barrier).
+// The per-workgroup partials are added up in a fixed order by k_moments_reduce (reproducible).
+constexpr int kMomPS = 17, kMomPanel = 112 * kMomPS;
+#ifndef RMH_MOM_ABL
+#define RMH_MOM_ABL 0   // ablation builds of tools/mom_ablation.sh (timing only, wrong moments)
+#endif
+
+// workgroup barrier for LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. for the
+// history stores of the record step to be acknowledged
+RMH_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// operand tiles of wavefront w: column tiles X0, X1 and row tiles X2, X3; its four MFMAs per k-block
+// are the 2 x 2 block (X2,X0) (X3,X0) (X2,X1) (X3,X1) -- ONE code path for all wavefronts, four
+// operand reads for four MFMAs.  Waves 0..5 cover 24 pairs (the free row slot beside tile 6 takes
+// the diagonal blocks' pairs); waves 6, 7 form two diagonal pairs each and waste two slots (bit
+// mask kMomKeep).  Together: all 28 pairs i >= j exactly once.
+__device__ constexpr int kMomTiles[8][4] = {{0, 1, 2, 3}, {0, 1, 4, 5}, {2, 3, 4, 5}, {0, 1, 6, 1},
+                                            {2, 3, 6, 3}, {4, 5, 6, 5}, {0, 2, 0, 2}, {4, 6, 4, 6}};
+__device__ constexpr int kMomKeep[8] = {15, 15, 15, 15, 15, 15, 9, 9};
+
+struct MomFused {
+    static constexpr int NT = 7, NTRI = 28, TPW = 4;
+    int xo[4];              // byte offsets of the wave's operand tiles in a panel (wave-uniform)
+    int po[TPW];            // offsets of its accumulator tiles in the workgroup's partial, -1: unused slot
+    double4_t acc[TPW];
+    bool all_live = true;   // every chain of the wave counts (wave-uniform)
+    int dbg_it = 0;
+
+    RMH_DEV void setup(int wave, bool live)
+    {
+        all_live = __all(live);
+        int tl[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tl[k] = kMomTiles[wave][k];
+            xo[k] = 16 * tl[k] * kMomPS * 8;
+        }
+        const int keep = kMomKeep[wave];
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            const int r = tl[2 + (tt & 1)], c = tl[tt >> 1];     // slot tt: row tile X2 / X3, column tile X0 / X1
+            po[tt] = ((keep >> tt) & 1) ? (r * (r + 1) / 2 + c) * 256 : -1;
+        }
+    }
+
+    // this wave's 16 chains into a panel; z = (theta, 1) for a live chain, 0 otherwise.
+    // * While MFMAs are in flight on a SIMD every other vector instruction of its two wavefronts
+    //   waits for a whole MFMA (64 cycles; measured with clock64: a round with a writer took
+    //   2048 + 64 x [vector instructions of the write] cycles), and the other seven wavefronts wait
+    //   for the writer at the next barrier.  So the write is LDS instructions only: addresses are
+    //   formed once per iteration before the first barrier (`wa`: row g, column cl of panel 0;
+    //   `ca`: row 0, column cl), everything else is an immediate offset.
+    // * Single ds_write_b64, as inline asm: left to itself the compiler pairs the stores into
+    //   ds_write2_b64, which wants 16-byte aligned elements -- with chains 8 bytes apart half the
+    //   lanes are not, and every such instruction is replayed at ~90 cycles.
+    // * Common path (every chain of the wave live): 28 stores of the state registers (rows > d of
+    //   the state are zero), then the constant 1 into row d by all four lanes of a chain (same
+    //   address, same value).  Only a wave with padding chains pays selects.
+    template <int OFF>
+    RMH_DEV static void lds_write(uint32_t addr, double v)
+    {
+        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+    }
+    template <int BUF, int S0>
+    RMH_DEV static void write_rows(uint32_t wa, bool live, bool all_live, const double (&th)[28])
+    {
+        if constexpr (S0 < 28) {
+            lds_write<BUF * kMomPanel * 8 + S0 * 4 * kMomPS * 8>(wa, all_live ? th[S0] : (live ? th[S0] : 0.0));
+            write_rows<BUF, S0 + 1>(wa, live, all_live, th);
+        }
+    }
+    template <int BUF>
+    RMH_DEV void write(uint32_t wa, uint32_t ca, int d, bool live, double one, const double (&th)[28]) const
+    {
+        if (RMH_MOM_ABL == 7) return;   // barriers only
+        if (all_live) write_rows<BUF, 0>(wa, true, true, th);
+        else write_rows<BUF, 0>(wa, live, false, th);
+        // row d <- 1 (0 for a padding chain; `one` holds that), after the zero the loop put there
+        if (d == 100) lds_write<BUF * kMomPanel * 8 + 100 * kMomPS * 8>(ca, one);
+        else if (d == 99) lds_write<BUF * kMomPanel * 8 + 99 * kMomPS * 8>(ca, one);
+        else if (d == 98) lds_write<BUF * kMomPanel * 8 + 98 * kMomPS * 8>(ca, one);
+        else lds_write<BUF * kMomPanel * 8 + 97 * kMomPS * 8>(ca, one);
+    }
+
+    // the running sums back from the workgroup's partial (L2): issued before the accept step so that
+    // the round trip is over when the first round needs them
+    RMH_DEV void begin(const double *partial_wg, bool first, int lane)
+    {
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+            if (!first && po[tt] >= 0 && RMH_MOM_ABL != 4) {
+                const double *src = partial_wg + po[tt] + lane;
+                acc[tt].x = src[0];
+                acc[tt].y = src[64];
+                acc[tt].z = src[128];
+                acc[tt].w = src[192];
+            }
+        }
+    }
+
+    // operands of one round: tile slot x, k-block q
+    struct Ops {
+        double v[4][4];
+    };
+    // One ds_read_b64 with an immediate offset: no address arithmetic between the MFMAs (every
+    // vector instruction of the phase is taken from the matrix pipe's time), and no merging into
+    // ds_read2_b64 (half the LDS rate).  The compiler does not see the read: `lds_barrier` and the
+    // waits below order it.
+    template <int OFF>
+    RMH_DEV static double lds_read(uint32_t addr)
+    {
+        double v;
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+        return v;
+    }
+    template <int BUF, int Q>
+    RMH_DEV static void fetch_q(const uint32_t (&base)[4], Ops &o)
+    {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            if (RMH_MOM_ABL == 2 || RMH_MOM_ABL == 7) o.v[x][Q] = 0.0;
+            else o.v[x][Q] = lds_read<BUF * kMomPanel * 8 + 32 * Q>(base[x]);
+        }
+    }
+    template <int Q>
+    RMH_DEV void multiply_q(const Ops &o)
+    {
+        if (RMH_MOM_ABL == 2 || RMH_MOM_ABL == 3 || RMH_MOM_ABL == 7) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) asm volatile("" ::"v"(o.v[x][Q]));
+            return;
+        }
+        acc[0] = mfma(o.v[2][Q], o.v[0][Q], acc[0]);
+        acc[1] = mfma(o.v[3][Q], o.v[0][Q], acc[1]);
+        acc[2] = mfma(o.v[2][Q], o.v[1][Q], acc[2]);
+        acc[3] = mfma(o.v[3][Q], o.v[1][Q], acc[3]);
+    }
+
+    // round k: multiply from `cur` while the next round's operands (buffer NB, when PREFETCH)
+    // arrive in `nxt` -- four reads, four MFMAs, four reads ...; the writer of round k+2 refills
+    // the buffer round k's operands came from (buffer 1 - NB) in the middle of the round
+    template <bool PREFETCH, int NB>
+    RMH_DEV void round(Ops &cur, Ops &nxt, const uint32_t (&base)[4], bool writer, uint32_t wa, uint32_t ca, int d,
+                       bool live, double one, const double (&th)[28])
+    {
+        // the operands of this round were read (inline asm) during the previous one and waited for
+        // by the s_waitcnt of the barrier in between; tell the compiler they are defined here
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(cur.v[x][q]));
+        if (PREFETCH) fetch_q<NB, 0>(base, nxt);
+        multiply_q<0>(cur);
+        if (PREFETCH) fetch_q<NB, 1>(base, nxt);
+        multiply_q<1>(cur);
+        if (writer) write<1 - NB>(wa, ca, d, live, one, th);
+        if (PREFETCH) fetch_q<NB, 2>(base, nxt);
+        multiply_q<2>(cur);
+        if (PREFETCH) fetch_q<NB, 3>(base, nxt);
+        multiply_q<3>(cur);
+    }
+
+    // one iteration: add sum over the workgroup's live chains of z z^T to its partial
+    RMH_DEV void step(double *panels, double *partial_wg, int wave, int lane, int d, bool live,
+                      const double (&th)[28])
+    {
+        if (RMH_MOM_ABL == 1) return;
+        if (RMH_MOM_ABL == 6) { // one barrier per iteration, nothing else: what lockstep costs the sampling phase
+            lds_barrier();
+            return;
+        }
+        const int g = lane >> 4, cl = lane & 15;
+#if RMH_MOM_ABL == 9
+        long long ts[12];
+        int nts = 0;
+#define RMH_TS() ts[nts++] = clock64()
+#else
+#define RMH_TS()
+#endif
+        RMH_TS();
+        // every address of the phase, formed here -- before the first barrier, while the early waves
+        // wait for the late ones anyway: gather (row m = cl, chain k = g) of the wave's four tiles,
+        // store (row g, column cl) and the constant's column, as LDS byte addresses of panel 0
+        const uint32_t pl = (uint32_t)(uintptr_t)panels;
+        const uint32_t p0 = pl + (uint32_t)(cl * kMomPS + g) * 8u;
+        uint32_t base[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) base[x] = p0 + (uint32_t)xo[x];
+        const uint32_t wa = pl + (uint32_t)(g * kMomPS + cl) * 8u, ca = pl + (uint32_t)cl * 8u;
+        const double one = live ? 1.0 : 0.0;
+        Ops a, b;
+        if (wave == 0) write<0>(wa, ca, d, live, one, th);
+        lds_barrier();                                           // panel 0 visible
+        RMH_TS();
+        fetch_q<0, 0>(base, a);
+        fetch_q<0, 1>(base, a);
+        fetch_q<0, 2>(base, a);
+        fetch_q<0, 3>(base, a);
+        if (wave == 1) write<1>(wa, ca, d, live, one, th);
+#pragma nounroll
+        for (int k = 0; k < 6; k += 2) {
+            // the barrier before a round publishes the next panel AND says that every wave has
+            // the current round's operands in registers (its reads complete before it arrives), so
+            // their buffer may be refilled
+            lds_barrier();
+            RMH_TS();
+            round<true, 1>(a, b, base, wave == k + 2, wa, ca, d, live, one, th);
+            lds_barrier();
+            RMH_TS();
+            round<true, 0>(b, a, base, wave == k + 3, wa, ca, d, live, one, th);
+        }
+        lds_barrier();
+        RMH_TS();
+        round<true, 1>(a, b, base, false, wa, ca, d, live, one, th);
+        lds_barrier();
+        RMH_TS();
+        round<false, 0>(b, a, base, false, wa, ca, d, live, one, th);
+        RMH_TS();
+#if RMH_MOM_ABL == 9
+        if (blockIdx.x == 3 && lane == 0 && dbg_it == 7)
+            printf("wave %d: wait %lld pro %lld | %lld %lld %lld %lld %lld %lld %lld %lld | total %lld\n", wave,
+                   ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[6] - ts[5],
+                   ts[7] - ts[6], ts[8] - ts[7], ts[9] - ts[8], ts[10] - ts[9], ts[10] - ts[0]);
+#endif
+        // (the next iteration's first write, panel 0's buffer: last read for round 6, complete
+        // before the barrier of round 7; its second write comes after a barrier of its own)
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            if (po[tt] >= 0 && RMH_MOM_ABL != 4) {
+                double *dst = partial_wg + po[tt] + lane;
+                dst[0] = acc[tt].x;
+                dst[64] = acc[tt].y;
+                dst[128] = acc[tt].z;
+                dst[192] = acc[tt].w;
+            }
+        }
+    }
+};
+
+template <int NW, bool ADAPT = false, bool PT = false, bool MOM = false>
 __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
     constexpr int NT = 7, S = 28, NF = 6, kFull = tri_tiles(NF) * 64; // six full row tiles: 84 tile images
@@ -385,6 +651,8 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
     double *Lt = Wimg + kFull, *Wt = Lt + kTailDoubles;
     double *mu = Wt + kTailDoubles;
     double *tab = mu + 4 * S;
+    double *panels = tab + kIcdfDoubles;   // MOM: two 16-chain panels (MomFused)
+    static_assert(!MOM || (NW == 8 && !ADAPT && !PT), "MomFused: eight wavefronts, plain random walk");
     for (int i = threadIdx.x; i < kFull; i += blockDim.x) {
         Limg[i] = pr.Ltiles[i];
         Wimg[i] = m.Wtiles[i];
@@ -423,12 +691,20 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
     keep.record<NT, 25>(run, ch, 0, c, g, active, th, lp);
     AdaptScale ad{0.0, 0.0, 1.0};
     if (ADAPT) ad.load(ch, c);
+    MomFused mom;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    double *mom_wg = nullptr;
+    const bool mom_live = active && c < run.mom_N;
+    if (MOM) {
+        mom.setup(wave_u, mom_live);
+        mom_wg = run.mom_partial + (int64_t)blockIdx.x * (MomFused::NTRI * 256);
+    }
 
     for (int64_t t = 0; t < run.T; ++t) {
         asm volatile("" ::: "memory");
         if (PT) pt.select(run, rng, cl);
         double xi[S];
-        T::template normals_fixed<13, 100, 3>(rng, ch.d, g, tab, xi);   // d = 97..100: 13 words
+        T::template normals_fixed<13, 100, MOM ? 2 : 3>(rng, ch.d, g, tab, xi);   // d = 97..100: 13 words
         // theta' = theta + scale * L xi: row tiles 0..5 on the matrix core, rows 96..99 on the VALU
         // (ADAPT: the chain's own scale times the unscaled image's product, as in k_run_rw)
         double4_t acc[NF];
@@ -490,6 +766,15 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         int code = acc_ok ? 1 : 0;
         if (PT) code = pt.swap(lane, acc_ok, parts, th, lp);
         if (ADAPT) ad.adapt(acc_ok, ch.adapt_target);
+        // adapt() after the step (sampler.py:88 -> adaptive.py:73-76), pooled over the chains.
+        // BEFORE the record: vmcnt counts loads and stores in one queue, so any wait on a load in
+        // the moment phase (the accumulators, a spilled address) would first drain the ~27 history
+        // stores of the record step (about 1100 cycles each time, measured with clock64)
+        if (MOM) {
+            mom.dbg_it = (int)t;
+            mom.begin(mom_wg, t == 0, lane);
+            mom.step(panels, mom_wg, wave_u, lane, ch.d, mom_live, th);
+        }
         if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = (uint8_t)code;
         keep.record<NT, 25>(run, ch, t + 1, c, g, active, th, lp);
     }

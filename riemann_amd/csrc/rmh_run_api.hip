@@ -4,7 +4,6 @@
 // the C ABI and rmh_host.hpp for the shared handle types.
 #include "rmh_host.hpp"
 
-#include <cstdlib>
 
 using namespace rmh;
 using namespace rmh::host;
@@ -149,7 +148,7 @@ static int acov_update(rmh_proposal *p)
 {
     // random walk: the one-workgroup device update (blocked Cholesky in LDS, k_acov_update): no
     // host round trip between the stretches of an adaptive run (tools/adaptcov_timing.py)
-    if (p->kind == kRW && p->d <= kAcovDeviceMaxDim && !getenv("RMH_ACOV_HOST")) return acov_update_device(p);
+    if (p->kind == kRW && p->d <= kAcovDeviceMaxDim && !policy(RMH_POLICY_ACOV_HOST)) return acov_update_device(p);
     const int d = p->d, D1 = d + 1, n = acov_ntri(p) * 256;
     std::vector<double> acc((size_t)n), Mm;
     if (rmh::comm_active()) {
@@ -202,7 +201,7 @@ static hipError_t launch_rw_plain(rmh_model *m, rmh_proposal *p, const ChainArgs
     RwArgs ra{p->d_Ltiles, nullptr, 0.0};
     switch (m->kind) {
     case kGauss:
-        if (m->ga.Wtail && p->d_Ltail && !getenv("RMH_NO_TAIL")) { // d = 97..100: rmh_run.hpp, k_run_rw_tail
+        if (m->ga.Wtail && p->d_Ltail && !policy(RMH_POLICY_NO_TAIL)) { // d = 97..100: rmh_run.hpp, k_run_rw_tail
             ra.Ltail = p->d_Ltail;
             return launch_gauss_rw_tail(m->ga, ra, c, r, adapt, g_stream);
         }
@@ -214,29 +213,53 @@ static hipError_t launch_rw_plain(rmh_model *m, rmh_proposal *p, const ChainArgs
     }
 }
 
-// Sampler.run with an AdaptCov random walk: fused launches between covariance updates.
-// Every state of a segment goes to a scratch history (the moments need all of them);
-// the entries the caller keeps are copied on.
+// first state number >= lo that [Nburn::Nthin] keeps (sampler.py:53-54), and its history entry
+static void first_kept(int64_t lo, int64_t nburn, int64_t nthin, int64_t *e, int64_t *k)
+{
+    const int64_t q = lo <= nburn ? 0 : (lo - nburn + nthin - 1) / nthin;
+    *e = nburn + q * nthin;
+    *k = q;
+}
+
+// Sampler.run with an AdaptCov proposal: one fused launch per stretch between covariance
+// updates.  Round 3, d = 97..100 random walk on the Gaussian model (BASELINE cfg 2's shape):
+// the sampling kernel accumulates the pooled moments of adapt() itself (MomFused, rmh_run.hpp)
+// and records straight into the caller's history -- no scratch history, no copies, two launches
+// per stretch (run, reduce) plus the update.  Everything else: every state of a stretch goes to
+// a scratch history that k_moments reads, and the entries the caller keeps are copied on.
 static int run_adaptcov(rmh_model *m, rmh_proposal *p, rmh_state *s, const ChainArgs &c, int64_t T,
                         int64_t nburn, int64_t nthin, rmh_history *h, int *launches)
 {
     int rc;
     const int64_t rows = 4 * s->ks, ld = s->ld;
-    if (!s->sc_theta) {
+    const bool fused = p->kind == kRW && m->kind == kGauss && m->ga.Wtail && p->d_Ltail && !c.adapt &&
+                       p->acov_NT == 7 && !policy(RMH_POLICY_NO_TAIL) && !policy(RMH_POLICY_ACOV_UNFUSED);
+    const int64_t nwg = fused ? gauss_rw_tail_workgroups(c.nblocks) : kAcovWGs;
+    const size_t need = (size_t)nwg * acov_ntri(p) * 256;
+    if (p->acov_partial_cap < need) {
+        (void)hipFree(p->d_acov_partial);
+        p->d_acov_partial = nullptr;
+        p->acov_partial_cap = 0;
+        if ((rc = dev_alloc(&p->d_acov_partial, need))) return rc;
+        p->acov_partial_cap = need;
+    }
+    if (!fused && !s->sc_theta) {
         if ((rc = dev_alloc(&s->sc_theta, (size_t)(kAcovChunk + 1) * rows * ld)) ||
             (rc = dev_alloc(&s->sc_logpost, (size_t)(kAcovChunk + 1) * ld)) ||
             (rc = dev_alloc(&s->sc_accept, (size_t)kAcovChunk * ld)))
             return rc;
         RMH_HIP(hipMemsetAsync(s->sc_theta, 0, (size_t)(kAcovChunk + 1) * rows * ld * sizeof(double), g_stream));
     }
-    if (!p->d_acov_partial && (rc = dev_alloc(&p->d_acov_partial, (size_t)kAcovWGs * acov_ntri(p) * 256))) return rc;
     if (T == 0 && h && nburn == 0) { // run(0): the history is the state on entry (sampler.py:49-50)
         RMH_HIP(hipMemcpyAsync(h->thetas, s->theta, (size_t)rows * ld * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
         RMH_HIP(hipMemcpyAsync(h->logpost, s->logpost, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
     }
     int64_t done = 0;
     while (done < T) {
-        int64_t seg = std::min<int64_t>(T - done, kAcovChunk);
+        // the proposal is fixed until the next update falls due (and a scratch history holds
+        // kAcovChunk iterations; the fused path has no such limit but keeps launches short
+        // enough for the partial sums to stay a few thousand terms deep)
+        int64_t seg = std::min<int64_t>(T - done, fused ? 1024 : kAcovChunk);
         for (int64_t i = 1; i <= seg; ++i)
             if (acov_due(p, p->acov_n + (double)i)) {
                 seg = i;
@@ -244,36 +267,57 @@ static int run_adaptcov(rmh_model *m, rmh_proposal *p, rmh_state *s, const Chain
             }
         RunArgs r{};
         r.T = seg;
-        r.nburn = 0;
-        r.nthin = 1;
-        r.h_theta = s->sc_theta;
-        r.h_logpost = s->sc_logpost;
-        r.h_accept = s->sc_accept;
-        if (p->kind == kHMC) {
-            HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT, p->minv};
-            RMH_HIP(m->kind == kGauss     ? launch_gauss_hmc(m->NT, m->ga, ha, c, r, false, g_stream)
-                    : m->kind == kMixture ? launch_mix_hmc(m->NT, m->ma, ha, c, r, false, g_stream)
-                                          : launch_logreg_hmc(m->NT, m->la, ha, c, r, false, g_stream));
-        } else {
-            RMH_HIP(launch_rw_plain(m, p, c, r, c.adapt != nullptr));
-        }
-        ++*launches;
-        if (h) {
-            for (int64_t i = (done == 0 ? 0 : 1); i <= seg; ++i) {
-                const int64_t e = done + i;
-                if (e < nburn || (e - nburn) % nthin) continue;
-                const int64_t k = (e - nburn) / nthin;
-                RMH_HIP(hipMemcpyAsync(h->thetas + k * rows * ld, s->sc_theta + i * rows * ld,
-                                       (size_t)rows * ld * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
-                RMH_HIP(hipMemcpyAsync(h->logpost + k * ld, s->sc_logpost + i * ld, (size_t)ld * sizeof(double),
-                                       hipMemcpyDeviceToDevice, g_stream));
+        if (fused) {
+            // states done .. done+seg of the run; number `done` was recorded by the previous stretch
+            int64_t e0, k0;
+            first_kept(done == 0 ? 0 : done + 1, nburn, nthin, &e0, &k0);
+            r.nburn = e0 - done;
+            r.nthin = nthin;
+            if (h) {
+                r.h_theta = h->thetas + k0 * rows * ld;
+                r.h_logpost = h->logpost + k0 * ld;
+                r.h_accept = h->accept ? h->accept + done * ld : nullptr;
             }
-            if (h->accept)
-                RMH_HIP(hipMemcpyAsync(h->accept + done * ld, s->sc_accept, (size_t)seg * ld, hipMemcpyDeviceToDevice, g_stream));
+            r.mom_partial = p->d_acov_partial;
+            r.mom_N = s->N;
+            RwArgs ra{p->d_Ltiles, nullptr, 0.0};
+            ra.Ltail = p->d_Ltail;
+            RMH_HIP(launch_gauss_rw_tail(m->ga, ra, c, r, false, g_stream));
+            ++*launches;
+            // adapt() after every step: the states 1..seg of the stretch, summed over the workgroups
+            RMH_HIP(launch_moments_reduce(p->d_acov_partial, nwg, acov_ntri(p) * 256, p->d_acov_acc, g_stream));
+        } else {
+            r.nburn = 0;
+            r.nthin = 1;
+            r.h_theta = s->sc_theta;
+            r.h_logpost = s->sc_logpost;
+            r.h_accept = s->sc_accept;
+            if (p->kind == kHMC) {
+                HmcArgs ha{p->eps, p->nsteps, p->d_chM, p->d_V, p->d_VT, p->minv};
+                RMH_HIP(m->kind == kGauss     ? launch_gauss_hmc(m->NT, m->ga, ha, c, r, false, g_stream)
+                        : m->kind == kMixture ? launch_mix_hmc(m->NT, m->ma, ha, c, r, false, g_stream)
+                                              : launch_logreg_hmc(m->NT, m->la, ha, c, r, false, g_stream));
+            } else {
+                RMH_HIP(launch_rw_plain(m, p, c, r, c.adapt != nullptr));
+            }
+            ++*launches;
+            if (h) {
+                for (int64_t i = (done == 0 ? 0 : 1); i <= seg; ++i) {
+                    const int64_t e = done + i;
+                    if (e < nburn || (e - nburn) % nthin) continue;
+                    const int64_t k = (e - nburn) / nthin;
+                    RMH_HIP(hipMemcpyAsync(h->thetas + k * rows * ld, s->sc_theta + i * rows * ld,
+                                           (size_t)rows * ld * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
+                    RMH_HIP(hipMemcpyAsync(h->logpost + k * ld, s->sc_logpost + i * ld, (size_t)ld * sizeof(double),
+                                           hipMemcpyDeviceToDevice, g_stream));
+                }
+                if (h->accept)
+                    RMH_HIP(hipMemcpyAsync(h->accept + done * ld, s->sc_accept, (size_t)seg * ld, hipMemcpyDeviceToDevice, g_stream));
+            }
+            // adapt() after every step: accumulate the states 1..seg of the segment
+            RMH_HIP(launch_moments(p->acov_NT, s->sc_theta, 1, seg + 1, (int)rows, ld, s->N, s->d,
+                                   p->d_acov_partial, kAcovWGs, p->d_acov_acc, g_stream));
         }
-        // adapt() after every step: accumulate the states 1..seg of the segment
-        RMH_HIP(launch_moments(p->acov_NT, s->sc_theta, 1, seg + 1, (int)rows, ld, s->N, s->d,
-                               p->d_acov_partial, kAcovWGs, p->d_acov_acc, g_stream));
         p->acov_n += (double)seg;
         done += seg;
         if (acov_due(p, p->acov_n) && (rc = acov_update(p))) return rc;
@@ -401,7 +445,7 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
                                       : launch_mix_pcn(m->NT, m->ma, ra, c, r, false, g_stream);
     } else if (K > 0) {
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
-        const bool tail = m->kind == kGauss && m->ga.Wtail && p->d_Ltail && !getenv("RMH_NO_TAIL");
+        const bool tail = m->kind == kGauss && m->ga.Wtail && p->d_Ltail && !policy(RMH_POLICY_NO_TAIL);
         if (tail) ra.Ltail = p->d_Ltail;
         e = tail                      ? launch_gauss_rw_tail(m->ga, ra, c, r, false, g_stream)
             : m->kind == kGauss       ? launch_gauss_pt(m->NT, m->ga, ra, c, r, g_stream)
@@ -426,13 +470,13 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
                 ra.blk_p[b] = p->blk_p[b];
             }
         }
-        if (m->kind == kGauss && m->ga.Wtail && p->d_Ltail && !getenv("RMH_NO_TAIL")) {
+        if (m->kind == kGauss && m->ga.Wtail && p->d_Ltail && !policy(RMH_POLICY_NO_TAIL)) {
             ra.Ltail = p->d_Ltail;   // d = 97..100: rows 96..99 on the VALU instead of a 7th row tile
             e = launch_gauss_rw_tail(m->ga, ra, c, r, adapt, g_stream);
         } else if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
         else if (m->kind == kChangepoint && adapt) e = launch_cp_generic(m->k, m->ca, ra, c, r, 1, g_stream);
         else if (m->kind == kChangepoint && p->L_is_diag && m->ca.ss_xp && m->ca.alpha_m1 == 0.0 &&
-                 !getenv("RMH_CP_NO_SS")) {
+                 !policy(RMH_POLICY_CP_NO_SS)) {
             // BASELINE cfg 5 (and the block-mixture proposal at fixed k): diagonal proposal factor,
             // alpha = 1: likelihood from sufficient statistics
             ra.Ldiag = p->d_Ldiag;
@@ -526,6 +570,7 @@ int rmh_proposal_set_adapt_cov(rmh_proposal_t p, const double *C0, double t_adap
     (void)hipFree(p->d_acov_acc);
     (void)hipFree(p->d_acov_partial);
     p->d_acov_acc = p->d_acov_partial = nullptr;
+    p->acov_partial_cap = 0;
     int rc = dev_alloc(&p->d_acov_acc, n);
     if (rc) return rc;
     RMH_HIP(hipMemset(p->d_acov_acc, 0, n * sizeof(double)));

@@ -16,8 +16,9 @@ RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (``torch.distributed.run``,
 ``mpirun`` wrappers, a shell loop) works, and nothing of the launcher is
 imported here.
 """
+import hashlib
 import os
-import pickle
+import secrets
 import socket
 import struct
 import tempfile
@@ -37,71 +38,216 @@ def shard_range(n_chains, rank, world):
 
 
 # ---------------------------------------------------------------- host group --
+# Wire format: fixed struct frames, no pickle (nothing a peer sends is ever executed).  A value is
+#   N                      None            b <u8>             bool
+#   i <i64>                int             f <f64>            float
+#   B <u64 n> bytes        bytes           s <u64 n> utf-8    str
+#   A <u8 len> dtype.str <u8 ndim> <u64 shape...> raw C-order data      numpy array (numeric dtypes)
+#   T / L <u32 n> values   tuple / list    (nesting <= 4)
+# A message is <u64 length> + one encoded value, at most _MAX_FRAME bytes.
+_MAX_FRAME = 1 << 30
+_MAX_DEPTH = 4
+_MAGIC = b"RMHRDZV2"
+
+
+def _enc(o, out, depth=0):
+    if depth > _MAX_DEPTH:
+        raise ValueError("riemann_amd.distributed: value nested too deeply for the wire format")
+    if o is None:
+        out.append(b"N")
+    elif isinstance(o, (bool, np.bool_)):
+        out.append(b"b" + struct.pack("<B", 1 if o else 0))
+    elif isinstance(o, (int, np.integer)):
+        out.append(b"i" + struct.pack("<q", int(o)))
+    elif isinstance(o, (float, np.floating)):
+        out.append(b"f" + struct.pack("<d", float(o)))
+    elif isinstance(o, (bytes, bytearray)):
+        out.append(b"B" + struct.pack("<Q", len(o)))
+        out.append(bytes(o))
+    elif isinstance(o, str):
+        b = o.encode("utf-8")
+        out.append(b"s" + struct.pack("<Q", len(b)))
+        out.append(b)
+    elif isinstance(o, np.ndarray):
+        if o.dtype.kind not in "biuf":
+            raise TypeError("riemann_amd.distributed: only numeric arrays travel (got %s)" % o.dtype)
+        a = np.ascontiguousarray(o)
+        ds = a.dtype.str.encode("ascii")
+        out.append(b"A" + struct.pack("<B", len(ds)) + ds + struct.pack("<B", a.ndim) +
+                   struct.pack("<%dQ" % a.ndim, *a.shape))
+        out.append(a.tobytes())
+    elif isinstance(o, (tuple, list)):
+        out.append((b"T" if isinstance(o, tuple) else b"L") + struct.pack("<I", len(o)))
+        for x in o:
+            _enc(x, out, depth + 1)
+    else:
+        raise TypeError("riemann_amd.distributed: %s does not travel over the host group" % type(o).__name__)
+
+
+def _dec(buf, pos, depth=0):
+    if depth > _MAX_DEPTH:
+        raise ValueError("bad frame: nesting")
+    tag = buf[pos:pos + 1]
+    pos += 1
+    if tag == b"N":
+        return None, pos
+    if tag == b"b":
+        return buf[pos] != 0, pos + 1
+    if tag == b"i":
+        return struct.unpack_from("<q", buf, pos)[0], pos + 8
+    if tag == b"f":
+        return struct.unpack_from("<d", buf, pos)[0], pos + 8
+    if tag in (b"B", b"s"):
+        (n,) = struct.unpack_from("<Q", buf, pos)
+        pos += 8
+        if n > len(buf) - pos:
+            raise ValueError("bad frame: length")
+        b = bytes(buf[pos:pos + n])
+        return (b if tag == b"B" else b.decode("utf-8")), pos + n
+    if tag == b"A":
+        nd = buf[pos]
+        dt = np.dtype(bytes(buf[pos + 1:pos + 1 + nd]).decode("ascii"))
+        pos += 1 + nd
+        if dt.kind not in "biuf":
+            raise ValueError("bad frame: dtype")
+        ndim = buf[pos]
+        pos += 1
+        shape = struct.unpack_from("<%dQ" % ndim, buf, pos)
+        pos += 8 * ndim
+        n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize if ndim else dt.itemsize
+        if n > len(buf) - pos:
+            raise ValueError("bad frame: array length")
+        a = np.frombuffer(bytes(buf[pos:pos + n]), dtype=dt).reshape(shape).copy()
+        return a, pos + n
+    if tag in (b"T", b"L"):
+        (n,) = struct.unpack_from("<I", buf, pos)
+        pos += 4
+        if n > len(buf):
+            raise ValueError("bad frame: count")
+        items = []
+        for _ in range(n):
+            x, pos = _dec(buf, pos, depth + 1)
+            items.append(x)
+        return (tuple(items) if tag == b"T" else items), pos
+    raise ValueError("bad frame: tag %r" % tag)
+
+
 def _send(sock, obj):
-    b = pickle.dumps(obj, protocol=4)
+    out = []
+    _enc(obj, out)
+    b = b"".join(out)
+    if len(b) > _MAX_FRAME:
+        raise ValueError("riemann_amd.distributed: message of %d bytes exceeds the frame limit" % len(b))
     sock.sendall(struct.pack("<Q", len(b)) + b)
 
 
+def _exactly(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(min(n - len(buf), 1 << 20))
+        if not chunk:
+            raise ConnectionError("riemann_amd.distributed: peer closed the rendezvous socket")
+        buf += chunk
+    return bytes(buf)
+
+
 def _recv(sock):
-    def exactly(n):
-        buf = bytearray()
-        while len(buf) < n:
-            chunk = sock.recv(n - len(buf))
-            if not chunk:
-                raise ConnectionError("riemann_amd.distributed: peer closed the rendezvous socket")
-            buf += chunk
-        return bytes(buf)
-    (n,) = struct.unpack("<Q", exactly(8))
-    return pickle.loads(exactly(n))
+    (n,) = struct.unpack("<Q", _exactly(sock, 8))
+    if n > _MAX_FRAME:
+        raise ConnectionError("riemann_amd.distributed: frame of %d bytes refused" % n)
+    obj, pos = _dec(_exactly(sock, n), 0)
+    if pos != n:
+        raise ConnectionError("riemann_amd.distributed: trailing bytes in a frame")
+    return obj
+
+
+def _is_loopback(host):
+    """True for 127.0.0.0/8, ::1 and ``localhost``."""
+    h = str(host).strip().lower()
+    return h == "localhost" or h == "::1" or h.startswith("127.") or h == "::ffff:127.0.0.1"
+
+
+def _token(key, extra=b""):
+    return hashlib.sha256(b"rmh-rdzv|" + str(key).encode("utf-8") + b"|" + extra).digest()[:16]
 
 
 class HostGroup(object):
     """The ranks of one job as a star over TCP sockets (rank 0 = hub): small host-side
-    collectives -- broadcast / all-gather of Python objects, barrier, max -- used to hand out
-    the RCCL id, and as the fallback where RCCL cannot form a communicator (several ranks on
-    one GPU).  Never on the data path: samples move over RCCL (:func:`pool`).
+    collectives -- broadcast / all-gather of plain values (None, bool, int, float, bytes, str,
+    numeric numpy arrays, tuples and lists of those), barrier, max -- used to hand out the RCCL id,
+    and as the fallback where RCCL cannot form a communicator (several ranks on one GPU).  Never on
+    the data path: samples move over RCCL (:func:`pool`).
 
-    Rendezvous: rank 0 listens on ``port`` of ``addr``.  With ``port=None`` it takes an
-    ephemeral port and publishes it in a file named after the launcher's process id and
-    MASTER_PORT under the temp directory (all ranks of a node share both), so no second
-    well-known port is needed next to the launcher's own MASTER_PORT store."""
+    Rendezvous.  Single node (``port=None``, the default): rank 0 listens on an ephemeral port of
+    **127.0.0.1 only** and publishes ``port token`` in a file readable by its user alone, named
+    after the launcher's process id and MASTER_PORT under the temp directory (all ranks of a node
+    share both) -- no second well-known port next to the launcher's own MASTER_PORT store.
+    Across nodes: ``port`` (``RMH_RDZV_PORT``) on ``addr`` (``MASTER_ADDR``); peers that are not
+    on the loopback interface are accepted only then.  Every peer opens with a fixed hello frame
+    -- magic, rank, 16-byte token (the file's random token, or one derived from the job key and
+    ``RMH_RDZV_TOKEN``) -- and a connection with a wrong hello, an out-of-range or duplicate rank,
+    or from a non-loopback address in single-node mode is dropped without disturbing the group.
+    Nothing received is ever unpickled or executed (fixed struct frames, see ``_enc``)."""
 
     def __init__(self, rank, world, addr="127.0.0.1", port=None, key=None, timeout=300.0):
         self.rank, self.world = int(rank), int(world)
         self._peers, self._hub, self._file = [], None, None
+        self.bound = None
         if self.world == 1:
             return
+        if not (0 <= self.rank < self.world):
+            raise ValueError("rank %d outside world of %d" % (self.rank, self.world))
         if key is None:
             key = "%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
         path = os.path.join(tempfile.gettempdir(), "rmh_rdzv_%s" % key)
         deadline = time.time() + timeout
+        env_tok = os.environ.get("RMH_RDZV_TOKEN", "").encode("utf-8")
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr if port is not None else "", int(port or 0)))
-            srv.listen(self.world)
-            srv.settimeout(timeout)
+            # loopback unless a multi-node rendezvous was asked for explicitly
+            bind_addr = addr if port is not None else "127.0.0.1"
+            remote_ok = port is not None and not _is_loopback(bind_addr)
+            srv.bind((bind_addr, int(port or 0)))
+            srv.listen(self.world + 4)
+            srv.settimeout(1.0)
+            self.bound = srv.getsockname()
             if port is None:
+                token = secrets.token_bytes(16)
                 tmp = "%s.%d" % (path, os.getpid())
-                with open(tmp, "w") as f:
-                    f.write("%d" % srv.getsockname()[1])
-                os.replace(tmp, path)     # atomic: readers see the whole number or nothing
+                fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+                with os.fdopen(fd, "w") as f:
+                    f.write("%d %s" % (self.bound[1], token.hex()))
+                os.replace(tmp, path)     # atomic: readers see the whole line or nothing
                 self._file = path
+            else:
+                token = _token(key, env_tok)
             peers = {}
             while len(peers) < self.world - 1:
-                c, _ = srv.accept()
-                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                if time.time() > deadline:
+                    srv.close()
+                    raise TimeoutError("riemann_amd.distributed: %d of %d ranks joined the rendezvous"
+                                       % (len(peers) + 1, self.world))
+                try:
+                    c, peer = srv.accept()
+                except socket.timeout:
+                    continue
+                r = self._hello(c, peer, token, remote_ok)
+                if r is None or r in peers:
+                    c.close()             # stray, foreign or duplicate connection: dropped
+                    continue
                 c.settimeout(timeout)
-                peers[_recv(c)] = c
+                peers[r] = c
             srv.close()
             self._peers = [peers[r] for r in range(1, self.world)]
         else:
             while True:
                 try:
-                    p = port
+                    p, token = port, _token(key, env_tok)
                     if p is None:
                         with open(path) as f:
-                            p = int(f.read())
+                            ps, ts = f.read().split()
+                        p, token = int(ps), bytes.fromhex(ts)
                     s = socket.create_connection((addr, int(p)), timeout=5.0)
                     break
                 except (OSError, ValueError):
@@ -110,8 +256,27 @@ class HostGroup(object):
                     time.sleep(0.05)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(timeout)
-            _send(s, self.rank)
+            s.sendall(_MAGIC + struct.pack("<ii", self.rank, self.world) + token)
+            if _exactly(s, 1) != b"\x01":
+                raise ConnectionError("riemann_amd.distributed: rank 0 refused the rendezvous")
             self._hub = s
+
+    def _hello(self, c, peer, token, remote_ok):
+        """Rank of a connecting peer, or None if the connection is not one of ours."""
+        try:
+            if not remote_ok and not _is_loopback(peer[0]):
+                return None
+            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            c.settimeout(5.0)
+            h = _exactly(c, len(_MAGIC) + 8 + 16)
+            r, w = struct.unpack_from("<ii", h, len(_MAGIC))
+            if (h[:len(_MAGIC)] != _MAGIC or w != self.world or not (1 <= r < self.world) or
+                    not secrets.compare_digest(h[len(_MAGIC) + 8:], token)):
+                return None
+            c.sendall(b"\x01")
+            return r
+        except (OSError, ConnectionError, struct.error):
+            return None
 
     @classmethod
     def from_env(cls, **kw):

@@ -354,3 +354,43 @@ def test_adaptive_covariance_run_of_zero_steps(ra):
     s.run(3)
     assert s._chain_thetas.shape == (4, 17, 15)
     np.testing.assert_array_equal(s._chain_thetas[0], th0)
+
+
+@pytest.mark.parametrize("d,N,squares", [(100, 333, False), (97, 2100, True)])
+def test_adaptive_covariance_fused_moments_vs_scratch_history(ra, d, N, squares):
+    """d = 97..100: the sampling kernel accumulates the pooled moments itself (MomFused,
+    rmh_run.hpp) and records straight into the caller's history; policy ACOV_UNFUSED keeps
+    round 2's scratch history + k_moments.  Same stream, same schedule: accept masks equal, states
+    and the adapted covariance equal to the rounding of two summation orders -- with burn-in and
+    thinning across update boundaries, without a history, and over a run-after-run sequence."""
+    from riemann_amd._lib import kernel_policy
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import AdaptCovRandomWalk
+    g = np.random.default_rng(d * N)
+    A = g.standard_normal((d, d))
+    Ct = A @ A.T / d + 0.3 * np.eye(d)
+    C0 = (0.3 / d) * np.eye(d)
+    th0 = g.standard_normal((N, d))
+    m = MultiGaussianDist(np.zeros(d), Ct)
+    out = []
+    for pol in ((), ("ACOV_UNFUSED",)):
+        with kernel_policy(*pol):
+            p = AdaptCovRandomWalk(C0, t_adapt=30, smooth_adapt=True, exact_squares=squares)
+            s = ra.Sampler(m, p, th0, seed=5, chain0=48)
+            s.run(37)
+            r1 = (s._chain_accept.copy(), s._chain_thetas.copy(), s._chain_logpost.copy())
+            s.run(50, 7, 5)
+            r2 = (s._chain_accept.copy(), s._chain_thetas.copy(), s._chain_logpost.copy())
+            s.run(23, record=False)
+            th, lp = s.current_state()
+            out.append((r1, r2, np.array(th), np.array(lp), p.C.copy(), p.L.copy(), p._SX.copy()))
+    a, b = out
+    for k in (0, 1):
+        np.testing.assert_array_equal(a[k][0], b[k][0])
+        np.testing.assert_allclose(a[k][1], b[k][1], rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(a[k][2], b[k][2], rtol=1e-8)
+    assert a[1][1].shape[0] == 9
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(a[4], b[4], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(a[5], b[5], rtol=1e-8, atol=1e-14)
+    np.testing.assert_allclose(a[6], b[6], rtol=1e-10, atol=1e-10)

@@ -225,7 +225,7 @@ def test_one_lane_per_chain_kernel_search_variants_vs_oracle(ra, orc, case):
     the full binary search; data sizes on both sides of the compile-time search depths, duplicate and
     unsorted x.  Forced here (by itself the kernel takes over at 65 536 chains); states, log
     posteriors and accept masks against the oracle's O(n) likelihood."""
-    import os
+    from riemann_amd._lib import kernel_policy
     from riemann_amd import workloads as W
     from riemann_amd.models import ChangepointRegression1D
     from riemann_amd.proposals import MetropolisRandomWalk
@@ -245,13 +245,10 @@ def test_one_lane_per_chain_kernel_search_variants_vs_oracle(ra, orc, case):
     d, N, T = 2 * k + 2, 700, 50
     th0 = truth + 0.01 * g.standard_normal((N, d))
     th0[:, :k] = np.sort(th0[:, :k], axis=1)
-    os.environ["RMH_CP_SS64"] = "1"
-    try:
+    with kernel_policy("CP_SS64"):
         s = ra.Sampler(ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=k),
                        MetropolisRandomWalk(np.diag(cdiag)), th0, seed=4, chain0=9)
         s.run(T)
-    finally:
-        del os.environ["RMH_CP_SS64"]
     om = orc.Changepoint(x, y, k, 1.0, 3.0, 5.0, 1.0, 1.0)
     th, st = th0.copy(), orc.rng_seed(4, N, chain0=9)
     ht, hl, acc = orc.run(om, orc.RandomWalk(np.diag(cdiag)), th, om.log_posterior(th), st, T)

@@ -154,7 +154,7 @@ def test_cfg5_three_kernels_agree_at_full_size(ra):
     """cfg5 at 65 536 chains through the three kernels that can run it -- k_cp_rw (O(n) likelihood,
     round 1), k_cp_rw_ss (sufficient statistics, four lanes per chain) and k_cp_rw_ss64 (one lane
     per chain): same stream, same accept decisions, states equal to rounding."""
-    import os
+    from riemann_amd._lib import kernel_policy
     from riemann_amd.models import ChangepointRegression1D
     from riemann_amd.proposals import MetropolisRandomWalk
     from riemann_amd.workloads import changepoint_data
@@ -162,17 +162,13 @@ def test_cfg5_three_kernels_agree_at_full_size(ra):
     th0 = truth + 0.01 * np.random.default_rng(5).standard_normal((N, 12))
     th0[:, :5] = np.sort(th0[:, :5], axis=1)
     out = {}
-    for name, env in (("ss64", {}), ("ss16", {"RMH_CP_SS16": "1"}), ("on", {"RMH_CP_NO_SS": "1"})):
-        os.environ.update(env)
-        try:
+    for name, pol in (("ss64", ()), ("ss16", ("CP_SS16",)), ("on", ("CP_NO_SS",))):
+        with kernel_policy(*pol):
             p = MetropolisRandomWalk(np.diag(cdiag))
             p.scale = 0.1
             s = ra.Sampler(ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=5), p, th0, seed=8)
             s.run(150, 0, 50)
             out[name] = (s._chain_accept.copy(), s._chain_thetas.copy(), s._chain_logpost.copy())
-        finally:
-            for k in env:
-                del os.environ[k]
     for name in ("ss16", "on"):
         np.testing.assert_array_equal(out["ss64"][0], out[name][0])
         np.testing.assert_allclose(out["ss64"][1], out[name][1], rtol=RTOL, atol=1e-12)
@@ -183,7 +179,7 @@ def test_cfg5_three_kernels_agree_at_full_size(ra):
 def test_cfg5_one_lane_per_chain_kernel_ragged_chain_counts(ra, orc, n):
     """k_cp_rw_ss64 owns 64 chains per wavefront: chain counts that leave its last wavefront one,
     two or three 16-chain blocks short (forced here; by itself it takes over at 65 536 chains)."""
-    import os
+    from riemann_amd._lib import kernel_policy
     from riemann_amd.models import ChangepointRegression1D
     from riemann_amd.proposals import MetropolisRandomWalk
     from riemann_amd.workloads import changepoint_data
@@ -192,13 +188,10 @@ def test_cfg5_one_lane_per_chain_kernel_ragged_chain_counts(ra, orc, n):
     th0[:, :5] = np.sort(th0[:, :5], axis=1)
     p = MetropolisRandomWalk(np.diag(cdiag))
     p.scale = 0.1
-    os.environ["RMH_CP_SS64"] = "1"
-    try:
+    with kernel_policy("CP_SS64"):
         s = ra.Sampler(ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=5), p, th0, seed=6, chain0=5)
         s.run(60, 7, 2)
         s.run(41)
-    finally:
-        del os.environ["RMH_CP_SS64"]
     om = orc.Changepoint(x, y, 5, 1.0, 3.0, 5.0, 1.0, 1.0)
     th, st = th0.copy(), orc.rng_seed(6, n, chain0=5)
     lp = om.log_posterior(th)

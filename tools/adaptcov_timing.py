@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Cost of the pooled Haario adaptation at the cfg2 size (65 536 chains, d = 100):
 plain random walk vs AdaptCovRandomWalk with the reference's float update test and with
-updates at perfect squares only.  Prints ms per 1000 iterations and launches."""
+updates at perfect squares only.  Prints ms per T (default 1000) iterations and launches.
+
+    python tools/adaptcov_timing.py [T] [float|squares|plain ...]"""
 import ctypes as C
 import os
 import sys
@@ -15,7 +17,8 @@ from riemann_amd import _lib, workloads as W                                 # n
 from riemann_amd.models import MultiGaussianDist                            # noqa: E402
 from riemann_amd.proposals import AdaptCovRandomWalk, MetropolisRandomWalk   # noqa: E402
 
-d, N, T = 100, 65536, 1000
+d, N, T = 100, 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+only = sys.argv[2:]
 Ct = W.corr_gauss_cov(d)
 m = MultiGaussianDist(np.zeros(d), Ct)
 th0 = np.random.default_rng(1).standard_normal((N, d)) @ np.linalg.cholesky(Ct).T
@@ -23,6 +26,8 @@ C0 = (2.38 ** 2 / d) * np.eye(d)
 for name, p in (("plain", MetropolisRandomWalk(C0)),
                 ("adaptcov float test", AdaptCovRandomWalk(C0, t_adapt=1000, smooth_adapt=True)),
                 ("adaptcov squares", AdaptCovRandomWalk(C0, t_adapt=1000, smooth_adapt=True, exact_squares=True))):
+    if only and not any(o in name for o in only):
+        continue
     s = ra.Sampler(m, p, th0, seed=3)
     s.run(20, record=False)
     t0 = time.perf_counter()

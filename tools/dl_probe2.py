@@ -9,5 +9,5 @@ for rep in range(3):
     a=s._host_thetas
     b=a
     while isinstance(b, np.ndarray) and b.base is not None: b=b.base
-    print("materialise %.1f ms = %.1f GB/s; base %s; pool bufs %s"%((t1-t0)*1e3, a.nbytes/(t1-t0)/1e9, type(b).__name__, [len(x) for x in s._pool._bufs] if s._pool else None))
+    print("materialise %.1f ms = %.1f GB/s; base %s; pool bufs %s"%((t1-t0)*1e3, a.nbytes/(t1-t0)/1e9, type(b).__name__, [x.nbytes for x in s._pool._allocs] if s._pool else None))
     del a, b

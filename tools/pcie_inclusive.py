@@ -10,6 +10,7 @@ import time
 import numpy as np
 
 import riemann_amd as ra
+from riemann_amd import _lib
 
 
 def main(chains=65536, its=200):
@@ -19,6 +20,7 @@ def main(chains=65536, its=200):
     C = A @ A.T + np.eye(d)
     s = ra.Sampler(ra.models.MultiGaussianDist(np.zeros(d), C), ra.proposals.MetropolisRandomWalk(2.38 ** 2 / d * C),
                    np.zeros((chains, d)), seed=1)
+    s._pool = _lib.PinnedPool(max_bytes=16 << 30)   # the default budget (4 GiB) is below this history
     s.run(its)
     s._chain_thetas              # warm-up: the first download page-locks its host buffer (kept by the
     #                              Sampler's pool and reused once nothing refers to the old history)

@@ -283,17 +283,36 @@ __global__ void __launch_bounds__(1024) k_acov_update(AcovUpdateArgs a)
     const int d = a.d, ds = acov_row_stride(d), tid = threadIdx.x, nth = blockDim.x;
     const double ntot = mom_at(a.acc, d, d);
     const double creg = a.creg;                                  // 1e-12 * mean(diag C0), adaptive.py:95-96
-    for (int idx = tid; idx < d * d; idx += nth) {
-        const int i = idx / d, j = idx - i * d;
-        const double cs = (mom_at(a.acc, i, j) - mom_at(a.acc, i, d) * mom_at(a.acc, j, d) / ntot) / (ntot - 1);
-        double cv;
-        if (a.smooth) cv = (ntot * cs + a.t_adapt * a.C0[idx]) / (ntot + a.t_adapt);
-        else if (ntot < a.t_adapt) cv = a.C0[idx];
-        else cv = cs + (i == j ? creg : 0.0);
-        if (a.marginalize && i != j) cv = 0.0;
-        cv = cv / a.f4;
-        A[i * ds + j] = cv;
-        a.Cout[idx] = cv;
+    // covariance from the moments, the expressions of the host version in the same order.  Division
+    // throughput is what this step costs (four f64 divisions per element; round 2's flat loop over
+    // all d^2 elements took 33 000 cycles of the kernel's 156 000, clock64): the matrix is symmetric
+    // and the factorisation reads its lower triangle only, so thread (ty, tx) of 32 x 32 forms the
+    // elements (ty + 32 a, tx + 32 b) with column <= row and stores each twice in the output --
+    // half the divisions, no integer division per element, the column sums SX once through LDS.
+    double *sx = A + d * ds;                                     // SX[j] = moments (j, d)
+    for (int j = tid; j < d; j += nth) sx[j] = mom_at(a.acc, j, d);
+    __syncthreads();
+    {
+        const int ty = tid >> 5, tx = tid & 31;
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+            for (int bj = 0; bj <= ai; ++bj) {
+                const int i = ty + 32 * ai, j = tx + 32 * bj;
+                if (i < d && j <= i) {
+                    const double c0 = a.C0[i * d + j];
+                    const double cs = (mom_at(a.acc, i, j) - sx[i] * sx[j] / ntot) / (ntot - 1);
+                    double cv;
+                    if (a.smooth) cv = (ntot * cs + a.t_adapt * c0) / (ntot + a.t_adapt);
+                    else if (ntot < a.t_adapt) cv = c0;
+                    else cv = cs + (i == j ? creg : 0.0);
+                    if (a.marginalize && i != j) cv = 0.0;
+                    cv = cv / a.f4;
+                    A[i * ds + j] = cv;
+                    a.Cout[i * d + j] = cv;
+                    a.Cout[j * d + i] = cv;
+                }
+            }
     }
     __syncthreads();
     for (int p0 = 0; p0 < d; p0 += 16) {
@@ -357,10 +376,22 @@ __global__ void __launch_bounds__(1024) k_acov_update(AcovUpdateArgs a)
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < d * d; idx += nth) {
-        const int i = idx / d, j = idx - i * d;
-        a.Lout[idx] = (j <= i) ? A[i * ds + j] / a.f2 : 0.0;
+    // L = chol / d^0.2 in place (one division per element), then the three output layouts from LDS
+    {
+        const int ty = tid >> 5, tx = tid & 31;
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) {
+                const int i = ty + 32 * ai, j = tx + 32 * bj;
+                if (i < d && j < d) {
+                    const double v = (j <= i) ? A[i * ds + j] / a.f2 : 0.0;
+                    A[i * ds + j] = v;
+                    a.Lout[i * d + j] = v;
+                }
+            }
     }
+    __syncthreads();
     // tile image: tile (i, s), s <= 4i+3, at index 2i(i+1)+s; lane l <- L[16i + (l&15)][4s + (l>>4)]
     const int ntile = 2 * a.NT * (a.NT + 1);
     for (int idx = tid; idx < ntile * 64; idx += nth) {
@@ -370,25 +401,25 @@ __global__ void __launch_bounds__(1024) k_acov_update(AcovUpdateArgs a)
         const int sidx = tl - 2 * i * (i + 1);
         const int row = 16 * i + (l & 15), col = 4 * sidx + (l >> 4);
         double v = 0.0;
-        if (row < d && col < d && col <= row) v = A[row * ds + col] / a.f2;
+        if (row < d && col < d && col <= row) v = A[row * ds + col];
         a.Limg[idx] = a.img_scale * v;
     }
     // rows 96.. for the VALU tail of k_run_rw_tail (d = 97..100), layout of pack_tail (rmh_api.hip)
     if (a.Ltail) {
-        for (int idx = tid; idx < 7 * 64; idx += nth) a.Ltail[idx] = 0.0;
-        __syncthreads();
-        for (int idx = tid; idx < 25 * 16; idx += nth) {
-            const int sg = idx >> 4, g = (idx >> 2) & 3, r = idx & 3;
+        for (int idx = tid; idx < 7 * 64; idx += nth) {
+            const int G = idx >> 6, g = (idx >> 4) & 3, e = idx & 15;   // [(G*4 + g)*16 + 4 q + r]
+            const int sg = 4 * G + (e >> 2), r = e & 3;
             const int row = 96 + r, col = 4 * sg + g;
-            if (row < d && col < d && col <= row)
-                a.Ltail[((sg / 4) * 4 + g) * 16 + 4 * (sg % 4) + r] = a.img_scale * (A[row * ds + col] / a.f2);
+            double v = 0.0;
+            if (sg < 25 && row < d && col < d && col <= row) v = a.img_scale * A[row * ds + col];
+            a.Ltail[idx] = v;
         }
     }
 }
 
 hipError_t launch_acov_update(const AcovUpdateArgs &a, hipStream_t st)
 {
-    const size_t lds = sizeof(double) * (size_t)a.d * acov_row_stride(a.d);
+    const size_t lds = sizeof(double) * ((size_t)a.d * acov_row_stride(a.d) + 128);   // matrix + SX
     return launch(k_acov_update, 16, 16, lds, st, a); // one workgroup of 1024 threads
 }
 

@@ -210,6 +210,11 @@ class Ranks(object):
                 os.close(keep)
         ok = self.group.allgather(self.rccl)
         if not all(ok):                # all or none: a half-formed communicator would hang
+            if self.rccl:              # formed here but not everywhere: give it back
+                try:
+                    _lib.call("rmh_comm_destroy")
+                except Exception:
+                    pass
             self.rccl = False
 
     def barrier(self):

@@ -10,7 +10,6 @@ PyTorch is imported).  Chains keep their random streams whatever the number of G
 keyed by global chain id), so the pooled sample is the single-GPU sample."""
 import ctypes as C
 import os
-import subprocess
 import sys
 
 import numpy as np
@@ -20,15 +19,10 @@ sys.path.insert(0, ROOT)
 
 if "RANK" not in os.environ:          # start one rank per GPU
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    from riemann_amd.distributed import spawn_ranks, visible_devices
     if n == 0:
-        from riemann_amd import _lib
-        nd = C.c_int()
-        _lib.call("rmh_device_count", C.byref(nd))
-        n = nd.value
-    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT="0")
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)],
-                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
-    sys.exit(max(p.wait() for p in procs))
+        n = visible_devices()
+    sys.exit(spawn_ranks([sys.executable, os.path.abspath(__file__)], n))   # 0 only if every rank succeeded
 
 import riemann_amd as ra                                              # noqa: E402
 from riemann_amd import _lib, distributed as D                        # noqa: E402

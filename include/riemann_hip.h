@@ -213,6 +213,18 @@ int rmh_history_download(rmh_history_t h, int64_t e0, int64_t e1, double *thetas
  * (examples/test_randomwalk.py:42).  Any output may be null. */
 int rmh_history_reduce(rmh_history_t h, int64_t e0, int64_t e1, int nlags, double *mean_dn,
                        double *var_dn, double *acf);
+
+/* The same reductions with the autocorrelation sums left as integers: acf_sums (nlags, d) =
+ * sum over the chains of round(rho_chain(k) * RMH_ACF_SCALE).  Integer sums add up exactly, so the
+ * sums of the ranks of a sharded job (riemann_amd.distributed.pool_history: one all-reduce) equal
+ * the single-process sums bit for bit; acf = acf_sums / (N * RMH_ACF_SCALE). */
+#define RMH_ACF_SCALE 1099511627776.0 /* 2^40 */
+int rmh_history_reduce_sums(rmh_history_t h, int64_t e0, int64_t e1, int nlags, double *mean_dn,
+                            double *var_dn, int64_t *acf_sums);
+/* Pooled first and second moments of entries [e0, e1) over all chains, formed on the device:
+ * moments = [count, sum theta (d), sum theta theta^T (d, d)] (the layout of rmh_allreduce_moments);
+ * d <= 111.  Pooled mean and covariance of a recorded run without the history leaving the GPU. */
+int rmh_history_moments(rmh_history_t h, int64_t e0, int64_t e1, double *moments);
 /* accept flags of iterations [t0,t1) -> (t1-t0, N) uint8 */
 int rmh_history_accept(rmh_history_t h, int64_t t0, int64_t t1, uint8_t *accept);
 int rmh_history_device_ptrs(rmh_history_t h, void **thetas_edn, void **logpost_en,
@@ -276,6 +288,11 @@ int rmh_allgather_samples(rmh_state_t s, double *pooled);
 int rmh_comm_last_ms(double *ms, int64_t *bytes_per_rank);
 int rmh_allreduce_moments(rmh_state_t s, double *moments);
 
+/* All-gather of recorded samples: entries e0, e0 + stride, ... < e1 of every rank's history ->
+ * pooled (n_sel, sum_r N_r, d) on every rank (chain blocks in rank order, ragged shards padded to
+ * the largest for one ncclAllGather per entry).  The thinned-sample counterpart of
+ * rmh_allgather_samples; all ranks must pass the same e0, e1, stride. */
+int rmh_allgather_history(rmh_history_t h, int64_t e0, int64_t e1, int64_t stride, double *pooled);
 /* ---- test hooks ---------------------------------------------------------- */
 /* the stream as the reference consumes it: xi (T,N,d), u (T,N) for chains
  * chain0..chain0+N-1, generated on the device */

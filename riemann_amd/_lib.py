@@ -90,6 +90,9 @@ SIGNATURES = {
     "rmh_allgather_samples": [_vp, _f64],
     "rmh_allreduce_moments": [_vp, _f64],
     "rmh_debug_rng_stream": [_u64s, _u64s, _i64, _int, _int, _f64, _f64],
+    "rmh_history_reduce_sums": [_vp, _i64, _i64, _int, _vp, _vp, _vp],
+    "rmh_history_moments": [_vp, _i64, _i64, _f64],
+    "rmh_allgather_history": [_vp, _i64, _i64, _i64, _f64],
     "rmh_debug_mfma": [_f64, _f64, _f64, _f64],
     "rmh_debug_set_kernel_policy": [_int, C.POINTER(_int)],
 }

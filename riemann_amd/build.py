@@ -51,17 +51,23 @@ def build(force=False, verbose=False):
         objs = list(ex.map(compile_one, SOURCES))
     # inline-asm DPP instructions are outside the compiler's hazard recogniser: scan the
     # disassembly of the objects that are about to be linked and refuse a hazardous build
-    import importlib.util
-    spec = importlib.util.spec_from_file_location(
-        "check_dpp_hazards", os.path.join(HERE, "..", "tools", "check_dpp_hazards.py"))
-    chk = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(chk)
-    total, bad = chk.check_objects(objs)
-    if bad:
-        raise RuntimeError("DPP data hazards in the built kernels (tools/check_dpp_hazards.py):\n  " +
-                           "\n  ".join(bad[:20]))
-    if verbose:
-        print("DPP hazard scan: %d DPP instructions, none hazardous" % total)
+    # (riemann_amd/_dpp_hazards.py; needs llvm-objdump -- RMH_SKIP_DPP_SCAN=1 builds without the scan
+    # where the tool is absent, at the builder's own risk)
+    from . import _dpp_hazards as chk
+    if os.environ.get("RMH_SKIP_DPP_SCAN") == "1":
+        if verbose:
+            print("DPP hazard scan skipped (RMH_SKIP_DPP_SCAN=1)")
+    elif not os.path.exists(chk.OBJDUMP):
+        raise RuntimeError("riemann_amd.build: %s not found -- the DPP hazard scan of the built kernels needs "
+                           "llvm-objdump (set LLVM_OBJDUMP, or RMH_SKIP_DPP_SCAN=1 to build without the scan)"
+                           % chk.OBJDUMP)
+    else:
+        total, bad = chk.check_objects(objs)
+        if bad:
+            raise RuntimeError("DPP data hazards in the built kernels (riemann_amd/_dpp_hazards.py):\n  " +
+                               "\n  ".join(bad[:20]))
+        if verbose:
+            print("DPP hazard scan: %d DPP instructions, none hazardous" % total)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"])
     return SO
 

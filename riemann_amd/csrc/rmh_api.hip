@@ -295,6 +295,16 @@ void rng_from_device_layout(const std::vector<uint64_t> &dev, int64_t N, int64_t
 namespace rmh {
 int comm_fail(int code, const std::string &msg) { return fail(code, msg); }
 hipStream_t comm_stream() { return g_stream; }
+int comm_hist_info(rmh_history_t h, rmh_state_t *s, double **thetas, int64_t *entries, int64_t *rows)
+{
+    if (!h) return fail(RMH_ERR_PARAM, "null history");
+    *s = h->s;
+    *thetas = h->thetas;
+    *entries = h->entries;
+    *rows = 4 * (int64_t)h->s->ks;
+    return RMH_OK;
+}
+
 int comm_state_info(rmh_state_t s, double **theta, int64_t *N, int64_t *ld, int *d, int *dp)
 {
     if (!s) return fail(RMH_ERR_PARAM, "null state");
@@ -1343,8 +1353,8 @@ int rmh_history_download(rmh_history_t h, int64_t e0, int64_t e1, double *thetas
 // integrated_time / ESS (riemann_amd/diagnostics.py; the reference prints
 // emcee.autocorr.integrated_time of one chain, examples/test_randomwalk.py:42).
 // mean_dn, var_dn: (d, N) parameter-major; acf: (nlags, d); any of them may be null.
-int rmh_history_reduce(rmh_history_t h, int64_t e0, int64_t e1, int nlags, double *mean_dn, double *var_dn,
-                       double *acf)
+static int history_reduce_impl(rmh_history_t h, int64_t e0, int64_t e1, int nlags, double *mean_dn, double *var_dn,
+                               double *acf, int64_t *acf_sums)
 {
     RMH_NEED_INIT();
     if (!h || e0 < 0 || e1 > h->entries || e1 - e0 < 2) return fail(RMH_ERR_PARAM, "history_reduce: bad entry range");
@@ -1352,20 +1362,78 @@ int rmh_history_reduce(rmh_history_t h, int64_t e0, int64_t e1, int nlags, doubl
     const rmh_state *s = h->s;
     const int64_t N = s->N, nblk = (N + 63) / 64;
     const int d = s->d, ng = nlags / 32;
-    double *dm = nullptr, *dv = nullptr, *dp = nullptr, *da = nullptr;
+    double *dm = nullptr, *dv = nullptr;
+    long long *dp = nullptr, *da = nullptr;
     int rc;
     if ((rc = dev_alloc(&dm, (size_t)d * N)) || (rc = dev_alloc(&dv, (size_t)d * N)) ||
         (rc = dev_alloc(&dp, (size_t)nblk * d * nlags)) || (rc = dev_alloc(&da, (size_t)nlags * d))) {
         (void)hipFree(dm); (void)hipFree(dv); (void)hipFree(dp); (void)hipFree(da);
         return rc;
     }
+    std::vector<long long> sums((size_t)nlags * d);
     hipError_t e = launch_hist_reduce(h->thetas, e0, e1, 4 * s->ks, s->ld, N, d, ng, dm, dv, dp, da, g_stream);
     if (e == hipSuccess && mean_dn) e = hipMemcpyAsync(mean_dn, dm, (size_t)d * N * sizeof(double), hipMemcpyDeviceToHost, g_stream);
     if (e == hipSuccess && var_dn) e = hipMemcpyAsync(var_dn, dv, (size_t)d * N * sizeof(double), hipMemcpyDeviceToHost, g_stream);
-    if (e == hipSuccess && acf) e = hipMemcpyAsync(acf, da, (size_t)nlags * d * sizeof(double), hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess && (acf || acf_sums))
+        e = hipMemcpyAsync(sums.data(), da, sums.size() * sizeof(long long), hipMemcpyDeviceToHost, g_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
     (void)hipFree(dm); (void)hipFree(dv); (void)hipFree(dp); (void)hipFree(da);
     RMH_HIP(e);
+    // the chain average of the integer sums (RMH_ACF_SCALE): one rounding, whatever the chain count
+    const double den = (double)N * RMH_ACF_SCALE;
+    for (size_t i = 0; i < sums.size(); ++i) {
+        if (acf) acf[i] = (double)sums[i] / den;
+        if (acf_sums) acf_sums[i] = (int64_t)sums[i];
+    }
+    return RMH_OK;
+}
+
+int rmh_history_reduce(rmh_history_t h, int64_t e0, int64_t e1, int nlags, double *mean_dn, double *var_dn,
+                       double *acf)
+{
+    return history_reduce_impl(h, e0, e1, nlags, mean_dn, var_dn, acf, nullptr);
+}
+
+int rmh_history_reduce_sums(rmh_history_t h, int64_t e0, int64_t e1, int nlags, double *mean_dn, double *var_dn,
+                            int64_t *acf_sums)
+{
+    return history_reduce_impl(h, e0, e1, nlags, mean_dn, var_dn, nullptr, acf_sums);
+}
+
+// [count, sum theta (d), sum theta theta^T (d, d)] over the chains and entries [e0, e1) of a recorded
+// history, on the matrix cores (k_moments: the pooled moment kernel of the covariance adaptation)
+int rmh_history_moments(rmh_history_t h, int64_t e0, int64_t e1, double *moments)
+{
+    RMH_NEED_INIT();
+    if (!h || !moments || e0 < 0 || e1 > h->entries || e1 <= e0)
+        return fail(RMH_ERR_PARAM, "history_moments: bad entry range");
+    const rmh_state *s = h->s;
+    const int d = s->d, D1 = d + 1, NT = nt_for_dim(D1);
+    if (NT < 0) return fail(RMH_ERR_PARAM, "history_moments: d > 111 is not supported by the moment kernel");
+    const int nwg = 512, ntri = NT * (NT + 1) / 2;
+    double *part = nullptr, *acc = nullptr;
+    int rc;
+    if ((rc = dev_alloc(&part, (size_t)nwg * ntri * 256)) || (rc = dev_alloc(&acc, (size_t)ntri * 256))) {
+        (void)hipFree(part);
+        return rc;
+    }
+    std::vector<double> hacc((size_t)ntri * 256);
+    hipError_t e = hipMemsetAsync(acc, 0, hacc.size() * sizeof(double), g_stream);
+    if (e == hipSuccess)
+        e = launch_moments(NT, h->thetas, e0, e1, 4 * s->ks, s->ld, s->N, d, part, nwg, acc, g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hacc.data(), acc, hacc.size() * sizeof(double), hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    (void)hipFree(part); (void)hipFree(acc);
+    RMH_HIP(e);
+    auto at = [&](int row, int col) {   // tile-pair layout of k_moments, lower triangle
+        if (row < col) std::swap(row, col);
+        const int i = row >> 4, j = col >> 4, t = i * (i + 1) / 2 + j, rr = row & 15;
+        return hacc[(size_t)t * 256 + (rr >> 2) * 64 + (rr & 3) * 16 + (col & 15)];
+    };
+    moments[0] = at(d, d);
+    for (int p = 0; p < d; ++p) moments[1 + p] = at(p, d);
+    for (int p = 0; p < d; ++p)
+        for (int q = 0; q < d; ++q) moments[1 + d + (size_t)p * d + q] = at(p, q);
     return RMH_OK;
 }
 

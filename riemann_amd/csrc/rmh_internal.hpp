@@ -249,7 +249,7 @@ hipError_t launch_cprj_eval(const CpRjArgs &m, const ChainArgs &c, double *lprio
 hipError_t launch_cprj_run(const CpRjArgs &m, const ChainArgs &c, const RunArgs &r, hipStream_t st);
 // per-chain means / variances and chain-averaged autocorrelations of history entries [e0, e1)
 hipError_t launch_hist_reduce(const double *hist, int64_t e0, int64_t e1, int rows, int64_t ld, int64_t N, int d,
-                              int ngroups, double *mean_dn, double *var_dn, double *partial, double *acf,
+                              int ngroups, double *mean_dn, double *var_dn, long long *partial, long long *sums,
                               hipStream_t st);
 hipError_t launch_rng_seed(uint64_t *rng, int64_t ld, uint64_t seed, uint64_t chain0,
                            hipStream_t st);

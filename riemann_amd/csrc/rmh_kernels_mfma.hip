@@ -429,12 +429,18 @@ hipError_t launch_acov_update(const AcovUpdateArgs &a, hipStream_t st)
 // (slot-major, lane-minor: conflict-free), and every step adds v_t v_{t-k} to the LG lag sums in
 // registers -- sum_t (x_t - m)(x_{t+k} - m), which is what the zero-padded FFT autocorrelation of
 // riemann_amd/diagnostics.py computes.  Lag group 0 also writes the chains' means and variances.
-// Per wave the 64 chains' normalised autocorrelations acov(k) / acov(0) are summed (fixed order)
-// into a partial that k_hist_acf_reduce adds up over the chain blocks: reproducible, no atomics.
+// Per wave the 64 chains' normalised autocorrelations rho(k) = acov(k) / acov(0) are summed as
+// INTEGERS, round(rho 2^40): integer addition does not care about order or grouping, so the sum over
+// chains is the same number whatever the shard boundaries of a multi-GPU job are (distributed.
+// pool_history: the ranks' sums add up to the single-process sum bit for bit); the quantisation is
+// 4.5e-13 per chain at most and averages out over the chains.  k_hist_acf_reduce adds the waves'
+// partials up over the chain blocks.
+constexpr double kAcfScale = 1099511627776.0;   // 2^40 (include/riemann_hip.h: RMH_ACF_SCALE)
+
 template <int LG>
 __global__ void __launch_bounds__(64) k_hist_acov(const double *hist, int64_t e0, int64_t e1, int rows, int64_t ld,
                                                   int64_t N, int d, int ngroups, int grp, double *mean_dn,
-                                                  double *var_dn, double *partial)
+                                                  double *var_dn, long long *partial)
 {
     extern __shared__ __attribute__((aligned(16))) double ring[];      // (lag0 + LG) x 64
     const int lane = threadIdx.x;
@@ -478,25 +484,26 @@ __global__ void __launch_bounds__(64) k_hist_acov(const double *hist, int64_t e0
     // diagnostics.autocorr_1d does)
 #pragma unroll
     for (int k = 0; k < LG; ++k) {
-        double r = live ? (a0 == 0.0 ? 1.0 : acc[k] / a0) : 0.0;
-        for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
-        if (lane == 0) partial[(cb * d + p) * (int64_t)(ngroups * LG) + lag0 + k] = r;
+        const double r = live ? (a0 == 0.0 ? 1.0 : acc[k] / a0) : 0.0;
+        long long q = __double2ll_rn(r * kAcfScale);
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        if (lane == 0) partial[(cb * d + p) * (int64_t)(ngroups * LG) + lag0 + k] = q;
     }
 }
 
-// acf[k][p] = (1/N) sum over the chain blocks, in order
-__global__ void k_hist_acf_reduce(const double *partial, int64_t nblk, int d, int K, int64_t N, double *acf)
+// sums[k][p] = sum over the chain blocks of the waves' integer sums
+__global__ void k_hist_acf_reduce(const long long *partial, int64_t nblk, int d, int K, long long *sums)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= d * K) return;
     const int p = idx / K, k = idx % K;
-    double s = 0.0;
+    long long s = 0;
     for (int64_t b = 0; b < nblk; ++b) s += partial[(b * d + p) * (int64_t)K + k];
-    acf[(int64_t)k * d + p] = s / (double)N;
+    sums[(int64_t)k * d + p] = s;
 }
 
 hipError_t launch_hist_reduce(const double *hist, int64_t e0, int64_t e1, int rows, int64_t ld, int64_t N, int d,
-                              int ngroups, double *mean_dn, double *var_dn, double *partial, double *acf,
+                              int ngroups, double *mean_dn, double *var_dn, long long *partial, long long *sums,
                               hipStream_t st)
 {
     constexpr int LG = 32;
@@ -516,7 +523,7 @@ hipError_t launch_hist_reduce(const double *hist, int64_t e0, int64_t e1, int ro
     }
     const int K = ngroups * LG;
     hipLaunchKernelGGL(k_hist_acf_reduce, dim3((unsigned)((d * K + 255) / 256)), dim3(256), 0, st, partial, nblk, d, K,
-                       N, acf);
+                       sums);
     return hipGetLastError();
 }
 

@@ -91,3 +91,110 @@ def accept_rate(chain_accept):
     """Mean of the accept flags (the reference derives it from chain diffs,
     examples/test_randomwalk.py:45)."""
     return float(np.mean(chain_accept))
+
+
+# ---- pooled diagnostics from per-rank reductions (riemann_amd.distributed.pool_history) ----------
+# A sharded job must report the numbers a single process would: bit for bit, not "to rounding",
+# or the same chains give a different R-hat on 4 GPUs than on 8.  Two devices make every sum over
+# chains independent of how the chains are split over ranks:
+#  * the autocorrelation sums arrive as integers (rmh_history_reduce_sums, RMH_ACF_SCALE): integer
+#    addition is exact;
+#  * sums of per-chain doubles (means, variances) are formed with math.fsum -- the correctly rounded
+#    value of the exact sum -- from the ranks' partials, each rank contributing its exact partial sum
+#    as three non-overlapping doubles (hi, lo, lo2: exact to 2^-150 of the partial).
+ACF_SCALE = 1099511627776.0   # 2^40, include/riemann_hip.h RMH_ACF_SCALE
+
+
+def exact_partial(x):
+    """The exact sum of the 1-D array ``x`` as three doubles (hi, lo, lo2)."""
+    import math
+    v = [float(t) for t in np.asarray(x, dtype=np.float64).ravel()]
+    hi = math.fsum(v)
+    lo = math.fsum(v + [-hi])
+    lo2 = math.fsum(v + [-hi, -lo])
+    return hi, lo, lo2
+
+
+def _sum_over_ranks(rows, allreduce, rank, world):
+    """Exact sums over all ranks of the rows of ``rows`` (q, n_local): each rank's exact partial
+    (three doubles per row) travels in its own slot of a zero-padded vector -- x + 0 + ... + 0 is
+    exact under any all-reduce order -- and every rank forms math.fsum over all partials."""
+    import math
+    rows = np.atleast_2d(np.asarray(rows, dtype=np.float64))
+    q = rows.shape[0]
+    buf = np.zeros((world, q, 3))
+    for i in range(q):
+        buf[rank, i] = exact_partial(rows[i])
+    buf = np.asarray(allreduce(buf.ravel()), dtype=np.float64).reshape(world, q, 3)
+    return np.array([math.fsum(buf[:, i, :].ravel().tolist()) for i in range(q)])
+
+
+def pooled_history_stats(piece, allreduce=None, rank=0, world=1, c=5.0):
+    """Diagnostics of a recorded run pooled over the chains of ALL ranks from per-rank reductions.
+
+    ``piece`` (one rank; Sampler.history_pieces or its numpy twin): ``n`` kept states, ``mean`` /
+    ``var`` (d, N_local) per-chain mean and biased variance, ``acf_sums`` (K, d) int64 integer
+    autocorrelation sums, ``mean_h`` / ``var_h`` (2, d, N_local) the same for the two half chains of
+    ``h`` states (absent when n < 4).  ``allreduce(vec)`` sums a float64 vector over the ranks (the
+    library's rmh_comm_allreduce_host, a gloo all_reduce, HostGroup ...); None for one process.
+    Returns pooled ``mean``, ``var`` (d,), ``acf`` (K, d), ``tau``, ``closed``, ``ess`` (d,),
+    ``rhat`` (d,) and ``chains``: every entry the same on every rank and the same whatever the
+    number of ranks the chains are sharded over."""
+    if allreduce is None:
+        if world != 1:
+            raise ValueError("pooled_history_stats: an allreduce is needed for more than one rank")
+        allreduce = lambda v: v                                           # noqa: E731
+    mean, var = np.asarray(piece["mean"]), np.asarray(piece["var"])
+    d, nloc = mean.shape
+    n = int(piece["n"])
+    cnt = np.zeros(world)
+    cnt[rank] = nloc
+    M = int(round(float(np.sum(allreduce(cnt)))))
+    # autocorrelation: integer sums, split into two exactly representable halves for the all-reduce
+    isum = np.asarray(piece["acf_sums"], dtype=np.int64)
+    hi, lo = (isum >> 32).astype(np.float64), (isum & 0xFFFFFFFF).astype(np.float64)
+    tot = np.asarray(allreduce(np.concatenate([hi.ravel(), lo.ravel()])), dtype=np.float64)
+    K = isum.shape[0]
+    thi, tlo = tot[:K * d].reshape(K, d), tot[K * d:].reshape(K, d)
+    den = float(M) * ACF_SCALE
+    acf = np.array([[float(int(thi[k, p]) * (1 << 32) + int(tlo[k, p])) / den for p in range(d)] for k in range(K)])
+    tau, closed = integrated_time_from_acf(acf, c)
+    out = {"chains": M, "acf": acf, "tau": tau, "closed": closed, "ess": M * n / np.maximum(tau, 1.0)}
+    # pooled mean and variance per parameter: chains have equal length, so the pooled mean is the mean
+    # of the chain means and the pooled variance the mean of var_c + (m_c - mu)^2
+    mu = _sum_over_ranks(mean, allreduce, rank, world) / M
+    out["mean"] = mu
+    out["var"] = _sum_over_ranks(var + (mean - mu[:, None]) ** 2, allreduce, rank, world) / M
+    # split R-hat (split_rhat above) over the 2M half chains
+    if "mean_h" in piece:
+        h = int(piece["h"])
+        mh = np.concatenate([piece["mean_h"][0], piece["mean_h"][1]], axis=1)          # (d, 2 N_local)
+        vh = np.concatenate([piece["var_h"][0], piece["var_h"][1]], axis=1)
+        M2 = 2 * M
+        W = _sum_over_ranks(vh * (h / (h - 1.0)), allreduce, rank, world) / M2
+        mu_h = _sum_over_ranks(mh, allreduce, rank, world) / M2
+        B = h * _sum_over_ranks((mh - mu_h[:, None]) ** 2, allreduce, rank, world) / (M2 - 1.0)
+        out["rhat"] = np.sqrt(((h - 1.0) / h * W + B / h) / W)
+    return out
+
+
+def history_pieces_numpy(x, nlags=128):
+    """The per-rank reductions of ``pooled_history_stats`` from a host array ``x`` (n, N, d) -- the
+    numpy restatement of rmh_history_reduce_sums (tests, and users without a device history)."""
+    x = np.asarray(x, dtype=np.float64)
+    n, N, d = x.shape
+    m = x.mean(axis=0)
+    xc = x - m
+    a0 = np.sum(xc * xc, axis=0)                                                      # (N, d)
+    sums = np.empty((nlags, d), dtype=np.int64)
+    for k in range(nlags):
+        ak = np.sum(xc[: n - k] * xc[k:], axis=0) if k < n else np.zeros((N, d))
+        rho = np.where(a0 == 0.0, 1.0, ak / np.where(a0 == 0.0, 1.0, a0))
+        sums[k] = np.rint(rho * ACF_SCALE).astype(np.int64).sum(axis=0)
+    piece = {"n": n, "mean": m.T.copy(), "var": x.var(axis=0).T.copy(), "acf_sums": sums}
+    h = n // 2
+    if h >= 2:
+        piece["h"] = h
+        piece["mean_h"] = np.stack([x[:h].mean(axis=0).T, x[h:2 * h].mean(axis=0).T])
+        piece["var_h"] = np.stack([x[:h].var(axis=0).T, x[h:2 * h].var(axis=0).T])
+    return piece

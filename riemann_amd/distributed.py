@@ -37,6 +37,47 @@ def shard_range(n_chains, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def spawn_ranks(argv, n, env=None, poll=0.1):
+    """Start ``n`` ranks of ``argv`` (a command line: list of str) on this node with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, and wait.  Returns 0 iff every rank exited 0.  A rank
+    that fails -- including one killed by a signal, which ``Popen`` reports as a negative code that
+    ``max()`` over the ranks' codes would hide behind the others' zeros -- is reported with its code,
+    and the remaining ranks are terminated so that they do not wait for it in a collective."""
+    import subprocess
+    import sys
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), MASTER_ADDR=base.get("MASTER_ADDR", "127.0.0.1"),
+                MASTER_PORT=base.get("MASTER_PORT", "0"))
+    procs = [subprocess.Popen(list(argv), env=dict(base, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+    codes = [None] * n
+    failed = False
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0) and not failed:
+                    failed = True
+                    print("rank %d exited with code %d; stopping the other ranks" % (r, codes[r]), file=sys.stderr)
+                    for q in procs:
+                        if q.poll() is None:
+                            q.terminate()
+        if any(c is None for c in codes):
+            time.sleep(poll)
+    return 0 if all(c == 0 for c in codes) else 1
+
+
+def visible_devices():
+    """Number of HIP devices, counted in a child process: a launcher that goes on to start its ranks
+    must not have initialised the GPU itself (fork + exec from a process that has is refused on the
+    GPU boxes of this pool)."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from riemann_amd import _lib; n = C.c_int(); "
+            "_lib.call('rmh_device_count', C.byref(n)); print(n.value)"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    return int(subprocess.check_output([sys.executable, "-c", code]).split()[-1])
+
+
 # ---------------------------------------------------------------- host group --
 # Wire format: fixed struct frames, no pickle (nothing a peer sends is ever executed).  A value is
 #   N                      None            b <u8>             bool
@@ -366,3 +407,52 @@ def pool(sampler):
     info = {"rccl_ranks": comm_ranks()[0], "allgather_bytes_per_rank": int(nb.value),
             "allgather_ms": float(ms.value), "pooled_chains": int(total.value)}
     return pooled, mean, cov, info
+
+
+def _allreduce_vec(v):
+    """Sum of a float64 vector over the ranks of the library's communicator (RCCL all-reduce)."""
+    from . import _lib
+    a = np.ascontiguousarray(v, dtype=np.float64).copy()
+    _lib.call("rmh_comm_allreduce_host", a, int(a.size), 0)
+    return a
+
+
+def pool_history(sampler, nlags=128, c=5.0, samples_every=None, allreduce=None, rank=None, world=None):
+    """Diagnostics of the last recorded ``run()`` pooled over the chains of ALL ranks without any
+    history leaving a GPU: every rank reduces its device history to per-chain
+    moments and integer autocorrelation sums (``Sampler.history_pieces``), the ranks exchange a few
+    small all-reduces, and every rank gets the same dictionary --
+
+    ``mean``, ``var`` (d,) pooled moments; ``cov`` (d, d) pooled covariance over all chains and kept
+    states (one all-reduce of the device-formed moment sums; d <= 111, else absent); ``acf`` (nlags,
+    d), ``tau``, ``closed``, ``ess`` (d,); ``rhat`` (d,) the split R-hat over the 2 M half chains of
+    all M chains; ``chains``.  mean / var / acf / tau / ess / rhat are bit for bit what one process
+    holding all chains reports (``Sampler.history_stats``): integer autocorrelation sums and
+    exactly rounded sums of the per-chain moments (``diagnostics.pooled_history_stats``).
+
+    ``samples_every=k`` adds ``samples``: kept states 0, k, 2k, ... of all chains, (n_sel, M, d), by
+    ncclAllGather (``rmh_allgather_history``) -- thinned samples, not only the final state.
+    ``allreduce`` / ``rank`` / ``world`` default to the library's RCCL communicator."""
+    import ctypes as C
+    from . import _lib, diagnostics as dg
+    if allreduce is None:
+        nr, rk = comm_ranks()
+        if nr == 0:
+            raise RuntimeError("pool_history: no communicator (comm_init first)")
+        allreduce, rank, world = _allreduce_vec, rk, nr
+    piece = sampler.history_pieces(nlags)
+    out = dg.pooled_history_stats(piece, allreduce, rank, world, c)
+    d = sampler.Npars
+    if d <= 111:
+        mom = np.empty(1 + d + d * d)
+        _lib.call("rmh_history_moments", sampler._hist, 0, sampler._kept, mom)
+        mom = np.asarray(allreduce(mom))
+        m1 = mom[1:1 + d] / mom[0]
+        out["cov"] = mom[1 + d:].reshape(d, d) / mom[0] - np.outer(m1, m1)
+    if samples_every:
+        k = int(samples_every)
+        nsel = (sampler._kept + k - 1) // k
+        pooled = np.empty((nsel, out["chains"], d))
+        _lib.call("rmh_allgather_history", sampler._hist, 0, sampler._kept, k, pooled)
+        out["samples"] = pooled
+    return out

@@ -381,35 +381,57 @@ class Sampler(object):
             self._host_logpost = np.empty((0, self.Nchains))
             self._host_accept = np.empty((0, self.Nchains), dtype=np.uint8)
 
+    def history_pieces(self, nlags=128):
+        """The reductions of the last recorded run() formed ON THE DEVICE (the history itself stays
+        there), in the form ``diagnostics.pooled_history_stats`` combines over ranks: ``n``,
+        ``mean`` / ``var`` (d, N) per chain and parameter, ``acf_sums`` (nlags, d) int64 integer
+        autocorrelation sums (rmh_history_reduce_sums), and the same moments of the two half
+        chains (``mean_h``, ``var_h`` (2, d, N), ``h``) for the split R-hat.  ``nlags``: 32, 64, ... 320."""
+        if self._state is None or not self._hist or self._kept < 2:
+            raise IndexError("history_stats: no device history (run() with at least two kept states first)")
+        N, d, n = self.Nchains, self.Npars, self._kept
+        mean, var, sums = np.empty((d, N)), np.empty((d, N)), np.empty((nlags, d), dtype=np.int64)
+        _lib.call("rmh_history_reduce_sums", self._hist, 0, n, int(nlags), mean.ctypes.data, var.ctypes.data,
+                  sums.ctypes.data)
+        piece = {"n": n, "mean": mean, "var": var, "acf_sums": sums}
+        h = n // 2
+        if h >= 2:
+            mh, vh = np.empty((2, d, N)), np.empty((2, d, N))
+            for k in range(2):
+                _lib.call("rmh_history_reduce_sums", self._hist, k * h, (k + 1) * h, 32, mh[k].ctypes.data,
+                          vh[k].ctypes.data, None)
+            piece.update(h=h, mean_h=mh, var_h=vh)
+        return piece
+
     def history_stats(self, nlags=128, c=5.0):
         """Diagnostics of the last recorded run() reduced ON THE DEVICE (the history itself stays
         there): ``mean``, ``var`` (N, d) per chain and parameter, ``acf`` (nlags, d) the
         chain-averaged autocorrelation functions, ``tau`` (d,) the integrated autocorrelation
         times (Sokal window ``c``), ``closed`` whether the window closed within ``nlags`` lags,
         ``ess`` = N * n / tau, and ``rhat`` (d,) the split R-hat over the 2N half-chains.
-        ``nlags``: 32, 64, ... 320."""
+        ``nlags``: 32, 64, ... 320.  The one-rank case of ``distributed.pool_history`` (same code:
+        a sharded job reports the same numbers bit for bit); ``pooled_mean`` / ``pooled_var`` are
+        the moments over all chains and kept states."""
         from .. import diagnostics as dg
-        if self._state is None or not self._hist or self._kept < 2:
-            raise IndexError("history_stats: no device history (run() with at least two kept states first)")
-        N, d, n = self.Nchains, self.Npars, self._kept
-        mean, var, acf = np.empty((d, N)), np.empty((d, N)), np.empty((nlags, d))
-        _lib.call("rmh_history_reduce", self._hist, 0, n, int(nlags), mean.ctypes.data, var.ctypes.data,
-                  acf.ctypes.data)
-        tau, closed = dg.integrated_time_from_acf(acf, c)
-        out = {"mean": mean.T, "var": var.T, "acf": acf, "tau": tau, "closed": closed,
-               "ess": N * n / np.maximum(tau, 1.0)}
-        # split R-hat (diagnostics.split_rhat) from the per-chain moments of the two halves
-        h = n // 2
-        if h >= 2:
-            mh, vh = np.empty((2, d, N)), np.empty((2, d, N))
-            for k in range(2):
-                _lib.call("rmh_history_reduce", self._hist, k * h, (k + 1) * h, 32, mh[k].ctypes.data,
-                          vh[k].ctypes.data, None)
-            means = np.concatenate([mh[0], mh[1]], axis=1)                      # (d, 2N)
-            W = (np.concatenate([vh[0], vh[1]], axis=1) * h / (h - 1.0)).mean(axis=1)
-            B = h * means.var(axis=1, ddof=1)
-            out["rhat"] = np.sqrt(((h - 1.0) / h * W + B / h) / W)
+        piece = self.history_pieces(nlags)
+        st = dg.pooled_history_stats(piece, c=c)
+        out = {"mean": piece["mean"].T, "var": piece["var"].T, "acf": st["acf"], "tau": st["tau"],
+               "closed": st["closed"], "ess": st["ess"], "pooled_mean": st["mean"], "pooled_var": st["var"]}
+        if "rhat" in st:
+            out["rhat"] = st["rhat"]
         return out
+
+    def history_moments(self):
+        """``(count, mean (d,), covariance (d, d))`` over all chains and kept states of the last
+        recorded run(), from one pass of the pooled moment kernel over the device history
+        (rmh_history_moments; d <= 111)."""
+        if self._state is None or not self._hist or self._kept < 1:
+            raise IndexError("history_moments: no device history")
+        d = self.Npars
+        mom = np.empty(1 + d + d * d)
+        _lib.call("rmh_history_moments", self._hist, 0, self._kept, mom)
+        mean = mom[1:1 + d] / mom[0]
+        return mom[0], mean, mom[1 + d:].reshape(d, d) / mom[0] - np.outer(mean, mean)
 
     def run_to_disk(self, prefix, Nsamples, Nburn=0, Nthin=1, chunk=1000):
         """``run(Nsamples, Nburn, Nthin)`` with the kept states streamed to disk instead of
@@ -455,12 +477,16 @@ class Sampler(object):
         if kept == 0:
             self.run(0, 1, 1)                                   # keeps nothing: no current state
         elif nb + (kept - 1) * nt != T:
-            last = np.asarray(fth[kept - 1])
-            _lib.call("rmh_state_set_theta", self._state, _lib.as_f64(np.atleast_2d(last)))
-            self._host_thetas = np.atleast_2d(last)[None].copy()
-            self._host_logpost = np.atleast_1d(np.asarray(flp[kept - 1]))[None].copy()
+            last = _lib.as_f64(np.atleast_2d(np.asarray(fth[kept - 1]))).copy()
+            last_lp = _lib.as_f64(np.atleast_1d(np.asarray(flp[kept - 1]))).copy()
+            if self._state is None:      # mixed plugins: the chains live on the host
+                self._th, self._lp = last.copy(), last_lp.copy()
+            else:
+                _lib.call("rmh_state_set_theta", self._state, last)
+                self._drop_history()
+            self._host_thetas = last[None].copy()
+            self._host_logpost = last_lp[None].copy()
             self._host_accept = np.zeros((0, self.Nchains), dtype=np.uint8)
-            self._drop_history()
             self._kept = 1
         return kept
 

@@ -137,13 +137,8 @@ def test_dpp_hazard_scanner_and_built_kernels():
     EXEC within five; the compiler does not check inside inline asm.  The build scans the
     disassembly of the objects it links (riemann_amd/build.py); here the scanner itself is
     checked and the built objects are scanned again (no GPU needed)."""
-    import importlib.util
     import os
-    spec = importlib.util.spec_from_file_location(
-        "check_dpp_hazards", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                          "tools", "check_dpp_hazards.py"))
-    chk = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(chk)
+    from riemann_amd import _dpp_hazards as chk
     fake = """
 	s_nop 0
 	s_nop 0

@@ -41,7 +41,19 @@ def _worker(rank, world, port, n_chains, out_dir):
     ht, hl, acc = orc.run(m, p, th, m.log_posterior(th), st, T)
     pooled = pool_samples(ht, n_chains)                  # (T+1, n_chains, d) on every rank
     mean, cov = pooled_moments(ht[-1])
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), pooled=pooled, mean=mean, cov=cov)
+    # pooled R-hat / tau / ESS from per-rank reductions (the history never travels): the product's
+    # combination code (riemann_amd.diagnostics.pooled_history_stats, used by distributed.pool_history)
+    # over a gloo all-reduce, the rank's reductions from the numpy twin of rmh_history_reduce_sums
+    import torch
+    from riemann_amd import diagnostics as dg
+
+    def allreduce(v):
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64).copy())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.numpy()
+    st = dg.pooled_history_stats(dg.history_pieces_numpy(ht, 32), allreduce, rank, world)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), pooled=pooled, mean=mean, cov=cov,
+             **{"st_" + k: np.asarray(v) for k, v in st.items()})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,11 +72,19 @@ def test_sharded_run_pools_to_the_single_process_run(tmp_path, world, n_chains):
     m, p = orc.Gaussian(np.zeros(d), Cov), orc.RandomWalk(0.5 * Cov / d)
     th = th0.copy()
     ht, _, _ = orc.run(m, p, th, m.log_posterior(th), orc.rng_seed(seed, n_chains), T)
+    from riemann_amd import diagnostics as dg
+    one = dg.pooled_history_stats(dg.history_pieces_numpy(ht, 32))       # one process, all chains
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         np.testing.assert_array_equal(z["pooled"], ht)
         np.testing.assert_allclose(z["mean"], ht[-1].mean(axis=0), rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(z["cov"], np.cov(ht[-1].T, bias=True), rtol=1e-10, atol=1e-12)
+        # pooled diagnostics: bit for bit the single-process values, on every rank
+        for k in ("mean", "var", "acf", "tau", "ess", "rhat", "chains"):
+            np.testing.assert_array_equal(z["st_" + k], np.asarray(one[k]), err_msg=k)
+    np.testing.assert_allclose(one["rhat"], dg.split_rhat(ht), rtol=1e-12)
+    np.testing.assert_allclose(one["mean"], ht.mean(axis=(0, 1)), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(one["var"], ht.reshape(-1, ht.shape[-1]).var(axis=0), rtol=1e-11)
 
 
 def test_shard_range_partitions_exactly():
@@ -102,6 +122,10 @@ def _host_worker(rank, world, key, n_chains, out_dir):
     ht, _, _ = orc.run(m, p, th, m.log_posterior(th), orc.rng_seed(seed, hi - lo, chain0=lo), T)
     pooled = np.concatenate(g.allgather(ht[-1]), axis=0)
     np.save(os.path.join(out_dir, "host_rank%d.npy" % rank), pooled)
+    from riemann_amd import diagnostics as dg
+    st = dg.pooled_history_stats(dg.history_pieces_numpy(ht, 32),
+                                 lambda v: np.sum(g.allgather(np.asarray(v, dtype=np.float64)), axis=0), rank, world)
+    np.savez(os.path.join(out_dir, "host_stats%d.npz" % rank), **{k: np.asarray(v) for k, v in st.items()})
     g.barrier()
     g.close()
 
@@ -124,8 +148,77 @@ def test_host_group_rendezvous_and_pooling(tmp_path, world, n_chains):
     m, p = orc.Gaussian(np.zeros(d), np.eye(d)), orc.RandomWalk(0.3 * np.eye(d))
     th = th0.copy()
     ht, _, _ = orc.run(m, p, th, m.log_posterior(th), orc.rng_seed(seed, n_chains), T)
+    from riemann_amd import diagnostics as dg
+    one = dg.pooled_history_stats(dg.history_pieces_numpy(ht, 32))
     for r in range(world):
         np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), "host_rank%d.npy" % r)), ht[-1])
+        z = np.load(os.path.join(str(tmp_path), "host_stats%d.npz" % r))
+        for k in ("mean", "var", "acf", "tau", "ess", "rhat", "chains"):
+            np.testing.assert_array_equal(z[k], np.asarray(one[k]), err_msg=k)
+
+
+def test_host_group_wire_format_and_rendezvous_hardening(tmp_path):
+    """ADVICE r2: no pickle on the wire, loopback bind by default, hello with rank check and token;
+    a stray or foreign connection is dropped and the group still forms."""
+    import struct
+    import threading
+    import time
+    import riemann_amd.distributed as D
+    src = open(D.__file__).read()
+    assert "import pickle" not in src and "pickle.loads" not in src
+    # round trip of every value kind that travels; unknown kinds are refused, not pickled
+    vals = (None, True, 7, -2.5, b"\x00\x01", "id", np.arange(6, dtype=np.int64).reshape(2, 3),
+            [np.float64(1.5), ("r", 3)])
+    out = []
+    D._enc(vals, out)
+    back, pos = D._dec(b"".join(out), 0)
+    assert pos == len(b"".join(out)) and back[:6] == vals[:6]
+    np.testing.assert_array_equal(back[6], vals[6])
+    assert back[7] == [1.5, ("r", 3)]
+    with pytest.raises(TypeError):
+        D._enc(object(), [])
+    with pytest.raises(TypeError):
+        D._enc(np.array(["a"], dtype=object), [])
+    with pytest.raises(ValueError):
+        D._dec(b"X", 0)
+    assert D._is_loopback("127.0.0.1") and D._is_loopback("localhost") and D._is_loopback("::1")
+    assert not D._is_loopback("10.0.0.5") and not D._is_loopback("192.168.1.2")
+    # rendezvous of two ranks in threads; a stranger connects first with garbage and with a wrong token
+    key = "harden_%d" % os.getpid()
+    res = {}
+
+    def run(rank):
+        g = D.HostGroup(rank, 2, key=key, timeout=30.0)
+        res[rank] = (g.bound, g.allgather(("rank", rank)))
+        g.barrier()
+        g.close()
+    t0 = threading.Thread(target=run, args=(0,))
+    t0.start()
+    path = os.path.join(__import__("tempfile").gettempdir(), "rmh_rdzv_%s" % key)
+    for _ in range(400):
+        if os.path.exists(path):
+            break
+        time.sleep(0.01)
+    port, tok = open(path).read().split()
+    assert oct(os.stat(path).st_mode & 0o777) == "0o600"          # the token is the user's alone
+    for hello in (b"GET / HTTP/1.0\r\n\r\n" + b"\0" * 32,
+                  D._MAGIC + struct.pack("<ii", 1, 2) + b"\0" * 16,           # wrong token
+                  D._MAGIC + struct.pack("<ii", 5, 2) + bytes.fromhex(tok)):    # rank out of range
+        c = socket.create_connection(("127.0.0.1", int(port)), timeout=5.0)
+        c.sendall(hello)
+        c.settimeout(5.0)
+        try:
+            assert c.recv(1) == b""                               # dropped without an answer
+        except (ConnectionError, socket.timeout):
+            pass
+        c.close()
+    t1 = threading.Thread(target=run, args=(1,))
+    t1.start()
+    t0.join(40)
+    t1.join(40)
+    assert res[0][1] == res[1][1] == [("rank", 0), ("rank", 1)]
+    assert res[0][0][0] == "127.0.0.1"                            # rank 0 listened on loopback only
+    assert not os.path.exists(path)
 
 
 def test_product_imports_no_torch():

@@ -73,6 +73,41 @@ def test_python_model_with_device_random_walk(ra):
     assert a._chain_thetas.shape == (3 + 4, 4, 2)
 
 
+def test_run_to_disk_with_a_python_model(ra, tmp_path):
+    """run_to_disk on the mixed-plugin path: the chains live on the host there; with
+    (T - Nburn) % Nthin != 0 the current state must become the last KEPT one, and the run continues
+    like an in-memory run()."""
+    from riemann_amd.proposals import MetropolisRandomWalk
+
+    class Gauss(ra.Model):
+        def log_prior(self, th):
+            return np.zeros(np.atleast_2d(th).shape[0])
+
+        def log_likelihood(self, th):
+            t = np.atleast_2d(th)
+            return -0.5 * np.sum(t * t, axis=1)
+
+        def pack(self):
+            pass
+
+        def unpack(self):
+            pass
+    th0 = np.random.default_rng(3).standard_normal((21, 3))
+    for T, nb, nt in ((23, 4, 5), (20, 0, 4)):
+        a = ra.Sampler(Gauss(), MetropolisRandomWalk(0.4 * np.eye(3)), th0, seed=11)
+        b = ra.Sampler(Gauss(), MetropolisRandomWalk(0.4 * np.eye(3)), th0, seed=11)
+        a.run(T, nb, nt)
+        kept = b.run_to_disk(str(tmp_path / "m"), T, nb, nt, chunk=6)
+        assert kept == a._chain_thetas.shape[0]
+        np.testing.assert_array_equal(np.load(str(tmp_path / "m_thetas.npy")), a._chain_thetas)
+        np.testing.assert_array_equal(np.load(str(tmp_path / "m_accept.npy")), a._chain_accept)
+        np.testing.assert_array_equal(b.current_state()[0], a.current_state()[0])
+        np.testing.assert_array_equal(b.current_state()[1], a.current_state()[1])
+        a.run(4)
+        b.run(4)
+        np.testing.assert_array_equal(b._chain_thetas, a._chain_thetas)
+
+
 def test_device_model_with_python_proposal(ra):
     """A user's Proposal (its own numpy generator) on a device Model: the Sampler supplies the
     accept uniforms from the chains' stream and the device evaluates the densities."""

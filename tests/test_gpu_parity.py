@@ -501,6 +501,27 @@ def test_rccl_pooling_entry_points_single_rank(ra):
         sa = ra.Sampler(m, pa, th0, seed=3)
         sa.run(30)
         with_comm = (sa._chain_thetas.copy(), pa.C.copy())
+        # pooled diagnostics of a recorded run over the communicator (one rank): the device
+        # reductions through RCCL == history_stats == the numpy twin of the reductions; thinned
+        # samples by all-gather; pooled covariance from the device-formed moment sums
+        from riemann_amd import diagnostics as dg
+        s.run(120, 10, 1)
+        x = s._chain_thetas
+        ph = D.pool_history(s, nlags=64, samples_every=25)
+        hs = s.history_stats(nlags=64)
+        one = dg.pooled_history_stats(dg.history_pieces_numpy(x, 64))
+        assert ph["chains"] == N
+        for k in ("acf", "tau", "ess", "rhat"):
+            np.testing.assert_array_equal(ph[k], hs[k], err_msg=k)
+            np.testing.assert_allclose(ph[k], one[k], rtol=1e-8, atol=1e-11, err_msg=k)
+        np.testing.assert_array_equal(ph["mean"], hs["pooled_mean"])
+        np.testing.assert_allclose(ph["mean"], x.mean(axis=(0, 1)), rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(ph["var"], x.reshape(-1, d).var(axis=0), rtol=1e-10)
+        np.testing.assert_allclose(ph["cov"], np.cov(x.reshape(-1, d).T, bias=True), rtol=1e-8, atol=1e-11)
+        np.testing.assert_array_equal(ph["samples"], x[::25])
+        cnt, hm, hc = s.history_moments()
+        assert cnt == N * x.shape[0]
+        np.testing.assert_allclose(hc, ph["cov"], rtol=1e-12, atol=1e-14)
     finally:
         _lib.call("rmh_comm_destroy")
     pb = AdaptCovRandomWalk(0.05 * np.eye(d), t_adapt=100, smooth_adapt=True)

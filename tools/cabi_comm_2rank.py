@@ -4,13 +4,16 @@ state shards, all-reduce of moments, and the covariance adaptation pooled over r
 
     python tools/cabi_comm_2rank.py --spawn 2          # starts its own ranks (no launcher needed)
     python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/cabi_comm_2rank.py
+    python tools/cabi_comm_2rank.py --scale            # the hardware check of an 8-GPU node, one command:
+        the correctness check above at every rank count the node has, then the bench lines of BASELINE
+        cfg4 (logistic HMC, 65 536 chains per GPU at 1/2/4/8 GPUs = 524 288 at 8) and cfg5 (changepoint
+        walk, 65 536 per GPU at 1/2/4 = 262 144 at 4), each with "pool": {"rccl_ranks": N, ...}
 
 No PyTorch is imported: the 128-byte RCCL id travels over riemann_amd.distributed.HostGroup.
 Rank r binds device r % RMH_NDEV (default: all visible devices).  On a one-GPU box both ranks
 share the device, which RCCL refuses ("duplicate GPU"): the script reports that and exits 0."""
 import ctypes as C
 import os
-import subprocess
 import sys
 
 import numpy as np
@@ -19,11 +22,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 if "--spawn" in sys.argv:
+    from riemann_amd.distributed import spawn_ranks
     n = int(sys.argv[sys.argv.index("--spawn") + 1])
-    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT="0")
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
-             for r in range(n)]
-    sys.exit(max(p.wait() for p in procs))
+    sys.exit(spawn_ranks([sys.executable, os.path.abspath(__file__)], n))   # 0 only if every rank succeeded
+
+if "--scale" in sys.argv:
+    from riemann_amd.distributed import spawn_ranks, visible_devices
+    ndev = visible_devices()
+    counts = [n for n in (1, 2, 4, 8) if n <= ndev]
+    rc = 0
+    for n in counts[1:]:
+        print("== correctness, %d ranks" % n, flush=True)
+        rc |= spawn_ranks([sys.executable, os.path.abspath(__file__)], n)
+    bench = os.path.join(ROOT, "bench.py")
+    for wl, most in (("logreg_hmc", 8), ("changepoint_rw", 4)):
+        for n in [c for c in counts if c <= most]:
+            print("== bench.py --gpus %d --workload %s" % (n, wl), flush=True)
+            rc |= spawn_ranks([sys.executable, bench, "--gpus", str(n), "--workload", wl, "--no-cpu-baseline"], n)
+    sys.exit(rc)
 
 import riemann_amd as ra                                             # noqa: E402
 from riemann_amd import _lib, distributed as D                        # noqa: E402
@@ -63,6 +79,17 @@ assert np.array_equal(pooled, full), "all-gather != single-process run"
 assert info["rccl_ranks"] == world and info["pooled_chains"] == N
 np.testing.assert_allclose(mean, full.mean(axis=0), rtol=1e-11, atol=1e-13)
 np.testing.assert_allclose(cov, np.cov(full.T, bias=True), rtol=1e-9, atol=1e-12)
+# pooled R-hat / tau / ESS of a recorded run from per-rank device reductions == one process, bit for bit;
+# thinned samples by all-gather
+s.run(60, 10, 1)
+ph = D.pool_history(s, nlags=32, samples_every=10)
+ref.run(60, 10, 1)
+hs = ref.history_stats(nlags=32)
+for k in ("acf", "tau", "ess", "rhat"):
+    assert np.array_equal(ph[k], hs[k]), "pooled %s != single-process value" % k
+assert np.array_equal(ph["mean"], hs["pooled_mean"]) and np.array_equal(ph["var"], hs["pooled_var"])
+assert np.array_equal(ph["samples"], ref._chain_thetas[::10]), "all-gather of thinned samples"
+np.testing.assert_allclose(ph["cov"], ref.history_moments()[2], rtol=1e-9, atol=1e-12)
 # covariance adaptation pooled over the ranks == single process over all chains (sums differ in order)
 C0 = 0.1 * np.eye(d)
 pa = AdaptCovRandomWalk(C0, t_adapt=100, smooth_adapt=True)

@@ -58,6 +58,7 @@ def workload(name, chains):
                     bound="mfma", label="cfg2: 100-d correlated Gaussian, random-walk MH",
                     omodel=lambda o: o.Gaussian(np.zeros(d), Ct), oprop=lambda o: o.RandomWalk(Cp),
                     twin=lambda t: (t.TwinGaussian(np.zeros(d), Ct), t.TwinRandomWalk(Cp), 20000),
+                    batched=lambda b: (b.BatchGaussian(np.zeros(d), Ct), dict(L_prop=np.linalg.cholesky(Cp)), 16384, 150),
                     cpu_sample=(65536, 200))
     if name in ("logreg_mala", "logreg_hmc"):   # configs[2] / configs[3]
         n, d = 10000, 100
@@ -73,6 +74,8 @@ def workload(name, chains):
                     omodel=lambda o: o.LogReg(X, y, 100.0), oprop=lambda o: o.HMC(eps, L, d),
                     twin=lambda t: ((lambda tm: (tm, t.TwinHMC(eps, L, tm.grad), 300 if L == 1 else 40))
                                     (t.TwinLogReg(X, y, 100.0))),
+                    batched=lambda b: (b.BatchLogReg(X, y, 100.0), dict(eps=eps, nsteps=L),
+                                       2048 if L == 1 else 1024, 6 if L == 1 else 2),
                     cpu_sample=(8192, 16) if L == 1 else (2048, 4))
     if name == "changepoint_rw":                # configs[4]
         x, y, truth, cdiag = W.changepoint_data()
@@ -86,7 +89,11 @@ def workload(name, chains):
                     theta0=th0, d=d, iters=2000, flops=900, bytes=8 * (d + 1), bound="hbm",
                     label="cfg5: changepoint k=5 (n=100), random-walk MH",
                     omodel=lambda o: o.Changepoint(x, y, k, 1.0, 3.0, 5.0, 1.0, 1.0),
-                    oprop=lambda o: o.RandomWalk(np.diag(cdiag), 0.1), cpu_sample=(65536, 1000))
+                    oprop=lambda o: o.RandomWalk(np.diag(cdiag), 0.1),
+                    batched=lambda b: (b.BatchChangepoint(x, y, k, 1.0, 3.0, 5.0, 1.0, 1.0),
+                                       dict(L_prop=0.1 * np.diag(np.sqrt(cdiag))), 16384, 60),
+                    ess_run=(200000, 200),      # tau_int ~ 2.7e3 iterations: a long thinned trace
+                    cpu_sample=(65536, 1000))
     if name == "pt_gauss":      # PTSampler, default ladder, on the cfg2 target
         d, K = 100, 5
         Ct = W.corr_gauss_cov(d)
@@ -157,6 +164,27 @@ def cpu_baseline(w, seed):
            "cpu": cpu_model(),
            "sample": "%d chains x %d iterations of the same workload, oracle/rmh_oracle.c "
                      "(OpenMP over chains), %.1f s" % (N, T, dt)}
+    bb = w.get("batched")
+    if bb is not None:   # the CPU number a practitioner would recognise: chains as a matrix, level-3 BLAS
+        from oracle import batched_twin
+        bm, kw, Nb, Tb = bb(batched_twin)
+        Nb = min(Nb, w["theta0"].shape[0])
+        try:
+            from threadpoolctl import threadpool_limits
+            lim = threadpool_limits(limits=threads)
+        except Exception:
+            lim = None
+        try:
+            batched_twin.run(bm, w["theta0"][:Nb], 1, seed, **kw)            # warm
+            dtb, accb = batched_twin.run(bm, w["theta0"][:Nb], Tb, seed, **kw)
+        finally:
+            if lim is not None:
+                lim.restore_original_limits() if hasattr(lim, "restore_original_limits") else lim.unregister()
+        out["batched_blas"] = {"value": Nb * Tb / dtb, "unit": "chain-iterations/s", "cores": threads, "kind": "port",
+                               "accept_rate": accb,
+                               "sample": "%d chains x %d iterations as one matrix: numpy + threaded BLAS "
+                                         "(theta @ X^T / triangular solves with N right-hand sides), "
+                                         "oracle/batched_twin.py, %.1f s" % (Nb, Tb, dtb)}
     tw = w.get("twin")
     if tw is not None:   # the reference-equivalent rate: numpy twin of the reference, 1 chain, 1 core
         from oracle import py_twin
@@ -171,15 +199,23 @@ def cpu_baseline(w, seed):
 
 
 def tau_estimate(w, seed):
-    """tau_int (min ESS parameter) from an untimed diagnostic run: 256 chains,
-    thinned long trace, on the device."""
+    """tau_int (the slowest parameter) and accept rate from an untimed diagnostic run: 256 chains, a
+    thinned trace, reduced ON THE DEVICE (Sampler.history_stats: chain-averaged autocorrelation
+    functions -> Sokal window; the history is not downloaded)."""
     import riemann_amd as ra
-    from riemann_amd import diagnostics as dg
-    T, thin = (20000, 20) if w["flops"] < 1e6 else (600, 1)
+    T, thin = w.get("ess_run") or ((20000, 20) if w["flops"] < 1e6 else ((600, 1) if w["flops"] < 2e7 else (150, 1)))
     s = ra.Sampler(w["model"], w["proposal"], w["theta0"][:256], seed=seed + 1000)
     s.run(T, T // 5, thin)
-    tau = dg.integrated_time(s._chain_thetas) * thin
-    return float(np.max(tau)), float(s._chain_accept.mean())
+    st = s.history_stats(nlags=128)
+    acc = _lib_accept_rate(s)
+    return float(np.max(st["tau"])) * thin, acc, bool(np.all(st["closed"])), s._kept
+
+
+def _lib_accept_rate(s):
+    from riemann_amd import _lib
+    a = np.empty((s._iters, s.Nchains), dtype=np.uint8)
+    _lib.call("rmh_history_accept", s._hist, 0, s._iters, a)
+    return float((a & 1).mean())
 
 
 class Ranks(object):
@@ -326,7 +362,11 @@ def measure(name, a, ranks, steps, warmup, iters=0, with_cpu=True, with_ess=True
                    "iterations_per_step": iters, "recorded": (not a.no_record),
                    "parallelism": "chains sharded by global id, %d rank(s)" % world},
         "roofline": {"bound": w["bound"], "achieved": ach, "peak": peak, "unit": unit,
-                     "frac": ach / peak, "traffic": (tr * N * iters if tr else None), "kernel_ms": kms,
+                     "frac": ach / peak, "traffic": (tr * N * iters if tr else None),
+                     "traffic_source": ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                        "this kernel, bytes per chain-iteration) x chains x iterations of this "
+                                        "launch; not measured in this run") if tr else None,
+                     "kernel_ms": kms,
                      "kernel_ms_over_ranks": [kms_lo, kms_hi],
                      "step_wall_ms": [round((b - a_) * 1e3, 3) for a_, b in zip([t0] + step_end, step_end)],
                      "algorithmic_bytes": bytes_,
@@ -351,9 +391,11 @@ def measure(name, a, ranks, steps, warmup, iters=0, with_cpu=True, with_ess=True
         out["config"]["chain_slots_per_gpu"] = a.chains
     if with_ess and world == 1 and not pt:
         try:
-            tau, acc = tau_estimate(w, a.seed)
-            out["ess"] = {"tau_int_max": tau, "accept_rate": acc, "ess_per_sec": value / tau,
-                          "estimator": "FFT autocorrelation, Sokal window c=5, 256 chains "
+            tau, acc, closed, nkept = tau_estimate(w, a.seed)
+            out["ess"] = {"tau_int_max": tau, "accept_rate": acc, "ess_per_sec": value / max(tau, 1.0),
+                          "window_closed": closed, "kept_states": nkept,
+                          "estimator": "chain-averaged autocorrelation functions reduced on the device "
+                                       "(rmh_history_reduce), Sokal window c=5, 256 chains "
                                        "(riemann_amd/diagnostics.py); parity unpinned: the reference's "
                                        "emcee.autocorr.integrated_time is not installed here"}
         except Exception as e:
@@ -392,10 +434,11 @@ def main():
     if a.workload is None and not a.no_also and ranks.world == 1:
         # short runs of the other BASELINE configs in the same process: cfg4 and cfg5 are
         # multi-GPU configurations, measured here as their per-GPU share (65 536 chains)
-        for name, st, wu, it in (("gauss_rw", 3, 1, 0), ("logreg_hmc", 2, 1, 20), ("changepoint_rw", 3, 1, 0)):
+        # (two warm-up launches: the first timed cfg2 step of round 2's line was 10 % slow after one)
+        for name, st, wu, it in (("gauss_rw", 3, 2, 0), ("logreg_hmc", 2, 2, 20), ("changepoint_rw", 3, 2, 0)):
             try:
                 r = measure(name, a, ranks, st, wu, iters=it, with_cpu=not a.no_cpu_baseline,
-                            with_ess=False, with_pool=False)
+                            with_ess=not a.no_ess, with_pool=False)
                 r["workload"] = name
                 also.append(r)
             except Exception as e:

@@ -7,6 +7,52 @@ from .. import _lib
 from .proposal import DeviceProposal
 
 
+# ---- the two adaptation rules, once, for every host-side user ---------------------------------------
+# (the mixed-plugin loop of samplers/sampler.py; tests replay the reference's fixtures through them:
+# tests/test_abi_and_host.py.  The device states them in csrc/rmh_run.hpp AdaptScale and
+# csrc/rmh_kernels_mfma.hip k_acov_update; the CPU checker under tests keeps its own restatement.)
+def adapt_scale_step(ada, moved, target):
+    """``AdaptScaleProposal.adapt`` (adaptive.py:25-35) for N chains at once, in place: ``ada`` (N, 3)
+    holds Nsamples, Naccepts, scale; ``moved`` (N,) whether the chain's state changed in this step.
+    The first call compares with ``last_theta = None`` and therefore always counts as a move
+    (adaptive.py:27 with :22)."""
+    m = np.where((ada[:, 0] == 0.0) | np.asarray(moved, dtype=bool), 1.0, 0.0)
+    ada[:, 0] += 1.0
+    ada[:, 1] += m
+    ratio = np.exp(1.0 / ada[:, 0])
+    up = ada[:, 1] / ada[:, 0] > target
+    ada[:, 2] = np.where(up, ada[:, 2] * ratio, ada[:, 2] / ratio)
+    return ada
+
+
+def adapt_cov_due(n, exact_squares=False):
+    """Is a covariance update due after the n-th ``adapt`` call?  adaptive.py:81-82: ``np.sqrt(n)**2
+    == n and n > 2`` -- literally (the float test also passes for about half of the non-squares),
+    or at perfect squares only."""
+    if not n > 2:
+        return False
+    r = np.sqrt(float(n))
+    return bool(np.floor(r + 0.5) ** 2 == n) if exact_squares else bool(r * r == n)
+
+
+def adapt_cov_update(count, SX, SX2, C0, t_adapt, smooth_adapt=False, marginalize=False):
+    """The covariance update of ``AdaptCovProposal.adapt`` (adaptive.py:83-102) from the moment sums
+    over ``count`` samples: returns (C, L) with C = cov / d^0.4 and L = cholesky(C) / d^0.2.  Raises
+    numpy's LinAlgError when the adapted covariance is not positive definite, as the reference does."""
+    d = C0.shape[0]
+    cs = (SX2 - np.outer(SX, SX) / count) / (count - 1.0)
+    if smooth_adapt:
+        cv = (count * cs + t_adapt * C0) / (count + t_adapt)
+    elif count < t_adapt:
+        cv = C0.copy()                                    # (:90 assigns this to an unused _cov; read as written)
+    else:
+        cv = cs + 1e-12 * (np.trace(C0) / d) * np.eye(d)
+    if marginalize:
+        cv = np.diag(np.diag(cv))
+    C = cv / float(d) ** 0.4
+    return C, np.linalg.cholesky(C) / float(d) ** 0.2
+
+
 class AdaptScaleProposal(DeviceProposal):
     """Adapts an overall scale towards a target acceptance rate (adaptive.py:11-35).
 

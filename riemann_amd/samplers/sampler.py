@@ -142,13 +142,9 @@ class Sampler(object):
         if not isinstance(self.proposal, DeviceProposal):
             for row in self._th:
                 self.proposal.adapt(row)                                           # :88
-        elif ada is not None:   # AdaptScaleProposal.adapt per chain (adaptive.py:25-35), as rmh_run.hpp AdaptScale
-            moved = np.where((ada[:, 0] == 0.0) | ok, 1.0, 0.0)
-            ada[:, 0] += 1.0
-            ada[:, 1] += moved
-            ratio = np.exp(1.0 / ada[:, 0])
-            up = ada[:, 1] / ada[:, 0] > self.proposal.target_accept_rate
-            ada[:, 2] = np.where(up, ada[:, 2] * ratio, ada[:, 2] / ratio)
+        elif ada is not None:   # AdaptScaleProposal.adapt per chain (adaptive.py:25-35)
+            from ..proposals.adaptive import adapt_scale_step
+            adapt_scale_step(ada, ok, self.proposal.target_accept_rate)
             self._publish_mixed_adapt()
             if self._mixed_adapt_cov():          # AdaptScaleCovRandomWalk: scale per chain AND pooled covariance
                 self._adapt_cov_mixed()
@@ -170,31 +166,17 @@ class Sampler(object):
         """AdaptCovProposal.adapt for every chain (adaptive.py:73-102), pooled as the device path pools it
         (rmh_run_api.hip, acov_update): sums over all chains, update when the per-chain count passes the
         reference's test, C and L pushed to the device proposal."""
-        p, st, d, th = self.proposal, self._mx_cov, self.Npars, self._th
+        from ..proposals.adaptive import adapt_cov_due, adapt_cov_update
+        p, st, th = self.proposal, self._mx_cov, self._th
         st["n"] += 1.0
         st["S"] += float(th.shape[0])
         st["SX"] += th.sum(axis=0)
         st["SX2"] += th.T @ th
-        n = st["n"]
-        if not n > 2:
+        n, nt = st["n"], st["S"]
+        if not adapt_cov_due(n, p.exact_squares):                                    # adaptive.py:81-82
             return
-        r = np.sqrt(n)
-        due = (np.floor(r + 0.5) ** 2 == n) if p.exact_squares else (r * r == n)     # adaptive.py:81-82
-        if not due:
-            return
-        nt, C0 = st["S"], p.C0
-        cs = (st["SX2"] - np.outer(st["SX"], st["SX"]) / nt) / (nt - 1.0)
-        if p.smooth_adapt:
-            cv = (nt * cs + p.t_adapt * C0) / (nt + p.t_adapt)
-        elif nt < p.t_adapt:
-            cv = C0.copy()
-        else:
-            cv = cs + 1e-12 * (np.trace(C0) / d) * np.eye(d)
-        if p.marginalize:
-            cv = np.diag(np.diag(cv))
-        Cn = cv / float(d) ** 0.4
         try:
-            L = np.linalg.cholesky(Cn) / float(d) ** 0.2                             # adaptive.py:101-102
+            Cn, L = adapt_cov_update(nt, st["SX"], st["SX2"], p.C0, p.t_adapt, p.smooth_adapt, p.marginalize)
         except np.linalg.LinAlgError:
             raise RuntimeError("AdaptCov: the adapted covariance is not positive definite")
         p.C, p.L, p._S, p._SX, p._SX2 = Cn, L, n, st["SX"].copy(), st["SX2"].copy()

@@ -174,3 +174,45 @@ def test_dpp_hazard_scanner_and_built_kernels():
     assert total == 1 and len(bad) == 1 and "block entry" in bad[0], bad
     total, bad = chk.main()
     assert total >= 600 and not bad, bad
+
+
+def test_host_adaptation_rules_replay_the_reference_fixtures():
+    """The ONE host statement of AdaptScaleProposal.adapt and of the Haario update
+    (riemann_amd/proposals/adaptive.py: adapt_scale_step, adapt_cov_due, adapt_cov_update -- what the
+    mixed-plugin Sampler calls) replayed on the runs recorded from the reference's classes: fed the
+    fixture's own accept flags / states they end in the fixture's adaptation state (g8, g14)."""
+    import glob
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # (the module imports the ctypes binding; loading the library needs no GPU)
+    sys.path.insert(0, root)
+    from riemann_amd.proposals.adaptive import adapt_cov_due, adapt_cov_update, adapt_scale_step
+    gold = os.path.join(root, "tests", "golden")
+    for f in sorted(glob.glob(os.path.join(gold, "g8_adapt_*.npz"))):
+        z = np.load(f)
+        acc = z["accept"]
+        ada = np.zeros((acc.shape[1], 3))
+        ada[:, 2] = 1.0
+        for t in range(acc.shape[0]):
+            adapt_scale_step(ada, acc[t] != 0, float(z["target"]))
+        np.testing.assert_array_equal(ada[:, 0], z["ad_n"])
+        np.testing.assert_array_equal(ada[:, 1], z["ad_acc"])
+        np.testing.assert_allclose(ada[:, 2], z["ad_scale"], rtol=1e-12)
+    for tag in ("smooth", "strict", "marg"):
+        z = np.load(os.path.join(gold, "g14_adaptcov_%s.npz" % tag))
+        th = z["thetas"]
+        for c in range(th.shape[1]):                       # three independent one-chain runs
+            d = th.shape[2]
+            SX, SX2, C, L = np.zeros(d), np.zeros((d, d)), z["C0"].copy(), None
+            for n in range(1, th.shape[0]):                # adapt() after every step, sampler.py:88
+                x = th[n, c]
+                SX += x
+                SX2 += np.outer(x, x)
+                if adapt_cov_due(n):
+                    C, L = adapt_cov_update(float(n), SX, SX2, z["C0"], float(z["t_adapt"]), bool(z["smooth"]),
+                                            bool(z["marginalize"]))
+            np.testing.assert_allclose(C, z["C_final"][c], rtol=1e-7, atol=1e-13)
+            np.testing.assert_allclose(L, z["L_final"][c], rtol=1e-7, atol=1e-13)
+    assert [n for n in range(1, 30) if adapt_cov_due(n, True)] == [4, 9, 16, 25]
+    assert adapt_cov_due(11) and adapt_cov_due(14) and not adapt_cov_due(2)   # the float test's extra hits

@@ -111,9 +111,10 @@ def test_cfg5_block_mixture_and_trans_dimensional_proposals_full_size_properties
     assert 0.01 < (acc & 1).mean() < 0.9
 
 
-@pytest.mark.parametrize("L,eps,T", [(1, 0.175, 5), (4, 0.12, 2)])
+@pytest.mark.parametrize("L,eps,T", [(1, 0.175, 5), (4, 0.12, 2), (10, 0.10, 1)])
 def test_logistic_10000x100_vs_oracle_with_eight_live_waves(ra, orc, L, eps, T):
-    """512 chains = four full workgroups of eight waves on the cfg3/cfg4 data against the oracle."""
+    """512 chains = four full workgroups of eight waves on the cfg3/cfg4 data against the oracle;
+    L = 10 is cfg4's own trajectory: nine gradient-only evaluations with all eight waves live."""
     from riemann_amd.models import LogisticRegression
     from riemann_amd.proposals import MALA, VanillaHMC
     from riemann_amd.workloads import logreg_data
@@ -234,3 +235,47 @@ def test_chain_count_limit_of_the_32_bit_buffer_offsets(ra):
     np.testing.assert_array_equal(small.current_state()[0], tail)
     with pytest.raises(ra.ParameterError, match="too many chains"):
         ra.Sampler(m, p, np.zeros((lim + 32, d)), seed=3)
+
+
+def test_late_rank_shards_of_the_multi_gpu_jobs(ra):
+    """The shards the LAST ranks of BASELINE cfg4 (8 x 65 536 chains: rank 7 starts at chain
+    458 752) and cfg5 (4 x 65 536: rank 3 at 196 608) run, against those chains of the whole job
+    run in one process: bit for bit (32-bit slot arithmetic and stream ids at the far end)."""
+    from riemann_amd.models import ChangepointRegression1D
+    from riemann_amd.proposals import MetropolisRandomWalk
+    from riemann_amd.workloads import changepoint_data
+    # cfg4: logistic 10 000 x 100, HMC L = 10
+    m, p, _ = _logreg(0.10, 10)
+    n4, a4 = 8 * N, 7 * N
+    th0 = (0.02 * np.random.default_rng(3).standard_normal((n4, 100))).astype(np.float64)
+    whole = ra.Sampler(m, p, th0, seed=1)
+    whole.run(1)
+    th_w, lp_w = whole.current_state()
+    acc_w = whole._chain_accept[:, a4:].copy()
+    th_w, lp_w = th_w[a4:].copy(), lp_w[a4:].copy()
+    del whole
+    part = ra.Sampler(m, p, th0[a4:], seed=1, chain0=a4)
+    part.run(1)
+    np.testing.assert_array_equal(part.current_state()[0], th_w)
+    np.testing.assert_array_equal(part.current_state()[1], lp_w)
+    np.testing.assert_array_equal(part._chain_accept, acc_w)
+    assert 0.3 < acc_w.mean() <= 1.0
+    del part, th0
+    # cfg5: changepoint model, random walk
+    x, y, truth, cdiag = changepoint_data()
+    n5, a5 = 4 * N, 3 * N
+    th0 = truth + 0.01 * np.random.default_rng(5).standard_normal((n5, 12))
+    th0[:, :5] = np.sort(th0[:, :5], axis=1)
+    pr = MetropolisRandomWalk(np.diag(cdiag))
+    pr.scale = 0.1
+    mc = ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=5)
+    whole = ra.Sampler(mc, pr, th0, seed=2)
+    whole.run(60, 0, 20)
+    ref = (whole._chain_thetas[:, a5:].copy(), whole._chain_logpost[:, a5:].copy(), whole._chain_accept[:, a5:].copy())
+    del whole
+    part = ra.Sampler(mc, pr, th0[a5:], seed=2, chain0=a5)
+    part.run(60, 0, 20)
+    np.testing.assert_array_equal(part._chain_thetas, ref[0])
+    np.testing.assert_array_equal(part._chain_logpost, ref[1])
+    np.testing.assert_array_equal(part._chain_accept, ref[2])
+    assert 0.05 < ref[2].mean() < 0.9

@@ -31,8 +31,10 @@ struct Keep {
         if (!run.h_theta || !active) return;
         double *dst = run.h_theta + k * (int64_t)(4 * ch.ks) * ch.ld;
         Tile<NT>::template store_rows<KS>(dst, ch.ld, c, g, KS > 0 ? KS : ch.ks, th);
-        // (raw buffer store: a flat one keeps a 64-bit address per lane alive across the iteration)
-        if (g == 0) buf_store(rsrc(run.h_logpost + k * ch.ld, ch.ld), (uint32_t)c * 8u, 0u, lp);
+        // (raw buffer store: a flat one keeps a 64-bit address per lane alive across the iteration; the
+        // lane offset is the state rows' own -- (g ld + c) 8 = 8 c on the lanes that store -- so that no
+        // second offset register lives through the loop)
+        if (g == 0) buf_store(rsrc(run.h_logpost + k * ch.ld, ch.ld), (uint32_t)(g * ch.ld + c) * 8u, 0u, lp);
     }
 };
 
@@ -673,10 +675,15 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
     const int64_t c = blk * 16 + cl;
     const int64_t slot = blk * 64 + lane;
 
+    // rows 100..111 of the state are padding (d <= 100): constants here, not three register pairs
+    // carried through the loop for a store of the zeros they were loaded as (round 2 spilled two of
+    // them); the stream state and the log posterior through raw buffer instructions (one 32-bit lane
+    // offset each instead of five 64-bit addresses held from entry to exit)
     double th[S];
     T::load_state(ch.theta, ch.ld, c, g, th);
-    double lp = ch.logpost[c];
-    Xo rng = xo_load(ch.rng, ch.nslots, slot);
+    th[25] = th[26] = th[27] = 0.0;
+    double lp = buf_load(rsrc(ch.logpost, ch.ld), (uint32_t)c * 8u, 0u);
+    Xo rng = xo_load_buf(ch.rng, ch.nslots, slot);
     PtLane pt;
     if (PT) { // MultiGaussianDist: log prior 0, so the state's parts are (0, logL) = (0, lp at beta = 1)
         pt.setup(run, cl, c);
@@ -748,17 +755,18 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         } else {
             thp[24] = th[24] + tl.finish();
         }
-        thp[25] = th[25];
-        thp[26] = th[26];
-        thp[27] = th[27];
+        thp[25] = thp[26] = thp[27] = 0.0;
         // log posterior: |W (theta' - mu)|^2, two row tiles in flight, then the four tail rows
         double y[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) y[s] = thp[s] - mu[4 * s + g];
         double parts[2] = {0.0, gauss_loglik(Wimg, Wt, m, lane, g, cl, y)};
         const double lpp = PT ? pt.tempered(parts) : combine_post(0.0, parts[1]);
+        if (MOM) mom.begin(mom_wg, t == 0, lane);   // (no stores in flight here: the record step comes last)
         const double u = T::accept_uniform(rng, g, cl);
-        bool acc_ok = mh_accept(lpp, lp, 0.0, u);
+        // (MOM: the logarithm's constants as literals at their use -- hoisted to kernel entry they are
+        // spilled there, and a scratch reload in the loop waits for every store in flight)
+        bool acc_ok = mh_accept<MOM>(lpp, lp, 0.0, u);
         if (PT) acc_ok = pt.within(acc_ok);
 #pragma unroll
         for (int s = 0; s < S; ++s) th[s] = acc_ok ? thp[s] : th[s];
@@ -772,17 +780,20 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         // stores of the record step (about 1100 cycles each time, measured with clock64)
         if (MOM) {
             mom.dbg_it = (int)t;
-            mom.begin(mom_wg, t == 0, lane);
             mom.step(panels, mom_wg, wave_u, lane, ch.d, mom_live, th);
         }
-        if (run.h_accept && active && g == 0) run.h_accept[t * ch.ld + c] = (uint8_t)code;
+        // (the accept byte through a buffer store at the state rows' lane offset / 8: a flat store keeps
+        // a 64-bit address per lane alive through the loop -- spilled in the MOM variant, and a scratch
+        // reload here waits for every store in flight)
+        if (run.h_accept && active && g == 0)
+            buf_store_u8(run.h_accept + t * ch.ld, ch.ld, (uint32_t)(g * ch.ld + c), (uint8_t)code);
         keep.record<NT, 25>(run, ch, t + 1, c, g, active, th, lp);
     }
     if (active) {
         T::store_state(ch.theta, ch.ld, c, g, th);
-        if (g == 0) ch.logpost[c] = lp;
+        if (g == 0) buf_store(rsrc(ch.logpost, ch.ld), (uint32_t)c * 8u, 0u, lp);
         if (ADAPT && g == 0) ad.store(ch, c);
-        xo_store(ch.rng, ch.nslots, slot, rng);
+        xo_store_buf(ch.rng, ch.nslots, slot, rng);
     }
 }
 

@@ -549,12 +549,19 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw_ss(CpArgs m, RwArgs pr, ChainA
 // truncate and one table read give #{x <= key} up to the (at most 2^S2 - 1) points of one bucket, which
 // S2 search steps resolve -- 1 + S2 dependent LDS round trips per boundary instead of floor(log2 n) + 1,
 // and this kernel's single wave per SIMD waits out every one of them.  Same counts, hence the same bits.
-template <int KC, int STEPS, int S2 = 0>
+// BLK (round 3): the reference's own fixed-k proposal, the block mixture of ChangepointRegression1DProp
+// (riemann/test_changepoint.py:18-56), on this layout -- as in k_cp_rw_ss<.., BLOCK> every sub-stream
+// draws one more word after the normals (accept uniform, u_cpx, u_cpv, u_sig), all four parked in the
+// chain's LDS row; the lane that carries the chain picks the block by the chained uniforms and scales
+// the diagonal factor of the other blocks' coordinates by 0 -- fma(0, xi, theta) = theta, the bits the
+// zeroed normals of the four-lane kernel give.  The three blocks are the reference's (k changepoint
+// positions, k + 1 heights, sigma): their ends are compile-time constants here (the launcher checks).
+template <int KC, int STEPS, int S2 = 0, bool BLK = false>
 __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
     constexpr int D = 2 * KC + 2, KP = KC + 1;
     constexpr int NT = (D + 15) / 16, S = 4 * NT, NS = (D + 3) / 4;
-    constexpr int DE = 2 * ((D + 2) / 2);        // doubles read back per chain: D normals + the uniform, even
+    constexpr int DE = 2 * ((D + (BLK ? 5 : 2)) / 2);   // doubles read back per chain: D normals + the uniform(s), even
     constexpr int TS = 2 * ((DE / 2) | 1);       // row stride: an odd number of 16-byte units (bank spread)
     using T = Tile<NT>;
     typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -620,7 +627,8 @@ __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainAr
             for (int b = 0; b < 4; ++b) w[b][mw] = xo_next(st[b]);
         double ua[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) ua[b] = u01(xo_next_if(st[b], g == 0));   // the accept word: sub-stream 0
+        for (int b = 0; b < 4; ++b)   // the accept word: sub-stream 0; BLK: one word of every sub-stream
+            ua[b] = BLK ? u01(xo_next(st[b])) : u01(xo_next_if(st[b], g == 0));
         constexpr int PL = 2;                     // passes evaluated in lockstep
 #pragma unroll
         for (int b0 = 0; b0 < 4; b0 += PL) {
@@ -639,7 +647,8 @@ __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainAr
 #pragma unroll
                 for (int sk = 0; sk < NS; ++sk)
                     if (4 * sk + g < D) row[4 * sk + g] = z[q * NS + sk];
-                if (g == 0) row[D] = ua[b0 + q];
+                if (BLK) row[D + g] = ua[b0 + q];
+                else if (g == 0) row[D] = ua[b0 + q];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -653,8 +662,18 @@ __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainAr
         }
         // ---- propose: theta' = theta + scale L xi, L diagonal (randomwalk.py:26)
         double tp[D];
+        if (BLK) { // block picked by the chained uniforms (test_changepoint.py:43-56, as k_cp_rw_ss)
+            int pk = -1;
+            if (dr[D + 3] < pr.blk_p[2]) pk = 2;
+            if (dr[D + 2] < pr.blk_p[1]) pk = 1;
+            if (dr[D + 1] < pr.blk_p[0]) pk = 0;
+            const double mb[3] = {pk == 0 ? 1.0 : 0.0, pk == 1 ? 1.0 : 0.0, pk == 2 ? 1.0 : 0.0};
 #pragma unroll
-        for (int j = 0; j < D; ++j) tp[j] = fma_(pr.Ldiag[j], dr[j], th[j]);
+            for (int j = 0; j < D; ++j) tp[j] = fma_(pr.Ldiag[j] * mb[j < KC ? 0 : (j < D - 1 ? 1 : 2)], dr[j], th[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < D; ++j) tp[j] = fma_(pr.Ldiag[j], dr[j], th[j]);
+        }
         // ---- prior (changepoint.py:128-160, alpha = 1: see k_cp_rw_ss)
         double prod = 1.0, dmin = __builtin_huge_val(), vsum = 0.0, vmin = __builtin_huge_val();
 #pragma unroll
@@ -763,8 +782,12 @@ static hipError_t cp_rw_ss_launch(const CpArgs &m, const RwArgs &p, const ChainA
     // one lane per chain (k_cp_rw_ss64: 4 waves x 64 chains per workgroup) once there are enough
     // chains to give every SIMD of the chip a wavefront of 64 (65 536: one each); below that the
     // four-lanes-per-chain kernel keeps four times as many waves in flight
-    if (p.nblk == 0 && (policy(RMH_POLICY_CP_SS64) || (c.nblocks >= 4096 && !policy(RMH_POLICY_CP_SS16)))) {
-        constexpr int DE = 2 * ((D + 2) / 2), TS64 = 2 * ((DE / 2) | 1);
+    // (block mixture: the reference's three blocks -- k positions, k + 1 heights, sigma -- whose ends the
+    // one-lane kernel holds as constants; any other block structure stays on the four-lane kernel)
+    const bool blk = p.nblk > 0;
+    const bool blk_ok = !blk || (p.nblk == 3 && p.blk_end[0] == KC && p.blk_end[1] == D - 1 && p.blk_end[2] == D);
+    if (blk_ok && (policy(RMH_POLICY_CP_SS64) || (c.nblocks >= 4096 && !policy(RMH_POLICY_CP_SS16)))) {
+        const int DE = 2 * ((D + (blk ? 5 : 2)) / 2), TS64 = 2 * ((DE / 2) | 1);
         const int nw = 4;
         const bool buckets = m.ss_nb > 0 && !policy(RMH_POLICY_CP_NO_BUCKETS);
         const size_t bkd = buckets ? (size_t)(((m.ss_nb + 2) / 2 + 1) & ~1) : 0;
@@ -780,6 +803,11 @@ static hipError_t cp_rw_ss_launch(const CpArgs &m, const RwArgs &p, const ChainA
         hipLaunchKernelGGL((k_cp_rw_ss64<KC, __VA_ARGS__>), grid, dim3(64 * nw), lds, st, m, p, c, r);    \
         return hipGetLastError();                                                                        \
     }
+            if (blk) { // fewer instantiations: the bucket table when the model has one, else run-time depth
+                if (buckets && m.ss_s2 == 2) RMH_CP_SS64(0, 2, true)
+                if (buckets && m.ss_s2 == 3) RMH_CP_SS64(0, 3, true)
+                RMH_CP_SS64(0, 0, true)
+            }
             if (buckets && m.ss_s2 == 2) RMH_CP_SS64(0, 2)
             if (buckets && m.ss_s2 == 3) RMH_CP_SS64(0, 3)
             switch (m.ss_steps) {

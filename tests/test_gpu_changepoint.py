@@ -51,7 +51,11 @@ def test_changepoint_rw_4096_chains(ra, orc):
     np.testing.assert_allclose(s._chain_logpost[fin], hl[fin], rtol=RTOL)
 
 
-def test_g13_changepoint_block_proposal_vs_reference_fixture(ra):
+@pytest.mark.parametrize("policy", [(), ("CP_SS64",)])
+def test_g13_changepoint_block_proposal_vs_reference_fixture(ra, policy):
+    """policy CP_SS64: the one-lane-per-chain kernel (k_cp_rw_ss64<.., BLK>), which takes over by itself
+    from 65 536 chains."""
+    from riemann_amd._lib import kernel_policy
     from riemann_amd.proposals import ChangepointRegression1DProp
     z = load("g13_changepoint_block")
     m = cp_model(z)
@@ -59,17 +63,21 @@ def test_g13_changepoint_block_proposal_vs_reference_fixture(ra):
     assert (p.P_cumprop_cpx, p.P_cumprop_cpv, p.P_cumprop_sig, p.P_cumprop_dim) == (0.2, 0.4, 0.6, 1.0)
     np.testing.assert_allclose(np.diag(p.L) ** 2, z["Cdiag"], rtol=1e-14)
     p.P_cumprop_cpv = 1.0        # as the fixture: cpx with 0.2, else cpv
-    s = ra.Sampler(m, p, z["theta0"], seed=int(z["seed"]))
-    s.run(160)
+    with kernel_policy(*policy):
+        s = ra.Sampler(m, p, z["theta0"], seed=int(z["seed"]))
+        s.run(160)
     check_run(z, s)
 
 
-def test_changepoint_block_proposal_many_chains_vs_oracle(ra, orc):
-    """Default probabilities (0.2 / 0.32 / 0.288, else the null move) on 4096 chains."""
+@pytest.mark.parametrize("policy", [(), ("CP_SS64",), ("CP_SS64", "CP_NO_BUCKETS")])
+def test_changepoint_block_proposal_many_chains_vs_oracle(ra, orc, policy):
+    """Default probabilities (0.2 / 0.32 / 0.288, else the null move) on 4096 chains (4100 on the
+    one-lane-per-chain kernel: a last wavefront of four chains)."""
+    from riemann_amd._lib import kernel_policy
     from riemann_amd.proposals import ChangepointRegression1DProp
     from riemann_amd import workloads as W
     x, y, truth, cdiag = W.changepoint_data()
-    k, d, N, T = 5, 12, 4096, 60
+    k, d, N, T = 5, 12, 4096 + (4 if policy else 0), 60
     from riemann_amd.models import ChangepointRegression1D
     m = ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 10, 1, 1, k=k)
     p = ChangepointRegression1DProp(m, 2.0)
@@ -77,8 +85,9 @@ def test_changepoint_block_proposal_many_chains_vs_oracle(ra, orc):
     g = np.random.default_rng(8)
     th0 = truth + 0.01 * g.standard_normal((N, d))
     th0[:, :k] = np.sort(th0[:, :k], axis=1)
-    s = ra.Sampler(m, p, th0, seed=21, chain0=77)
-    s.run(T)
+    with kernel_policy(*policy):
+        s = ra.Sampler(m, p, th0, seed=21, chain0=77)
+        s.run(T)
     om = orc.Changepoint(x, y, k, 1.0, 3.0, 5.0, 1.0, 1.0)
     op = orc.BlockRandomWalk(np.diag(np.diag(p.L) ** 2), [k, k + 1, 1], [0.2, 0.4, 0.6], scale=0.5)
     th = th0.copy()

@@ -928,47 +928,6 @@ struct CpRj {
         return v;
     }
 
-    // log_prior for k changepoints (k' = k+1 pieces), changepoint.py:128-160
-    static RMH_DEV double log_prior(const CpRjArgs &m, const double *ktab, const State &s, int g)
-    {
-        const CpArgs &b = m.base;
-        double pv = 0.0, ps = 0.0;
-#pragma unroll
-        for (int j0 = 0; j0 < KP; j0 += 4) {
-            // lane g takes piece j0 + g (static indices through selects)
-            double v = 1.0, lo = b.xmin, hi = b.xmax;
-            const int j = j0 + g;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (j0 + q < KP && g == q) {
-                    v = s.cpv[j0 + q];
-                    lo = (j0 + q == 0) ? b.xmin : s.cpx[(j0 + q - 1 < KD && j0 + q >= 1) ? j0 + q - 1 : 0];
-                    hi = (j0 + q < KD) ? s.cpx[j0 + q < KD ? j0 + q : 0] : b.xmax;
-                }
-            }
-            const bool valid = j <= s.k;
-            if (j == s.k) hi = b.xmax; // the last piece ends at xmax (cpx beyond k is +inf)
-            const double vv = valid ? v : 1.0, dx = valid ? hi - lo : 1.0;
-            // (alpha - 1) log(v): with alpha = 1 the product is +-0 for 0 < v < inf and NaN otherwise,
-            // exactly as numpy evaluates it -- the same bits without the logarithm
-            double la;
-            if (b.alpha_m1 == 0.0) la = (vv > 0.0 && vv < __builtin_huge_val()) ? 0.0 : __builtin_nan("");
-            else la = b.alpha_m1 * log_full(vv);
-            const double tv = ((b.c_v + la) - b.beta * vv) - b.lgam_alpha;
-            const double ts = log_full(dx);
-            pv += valid ? tv : 0.0;
-            ps += valid ? ts : 0.0;
-        }
-        pv = sum4(pv);
-        ps = sum4(ps);
-        const double *kt = ktab + 4 * (s.k + 1);
-        double p2 = log_full(1.0 / (s.sig * s.sig));
-        if (s.sig < 0.0) p2 = __builtin_nan("");
-        double logP = ((kt[0] + pv) + ((kt[1] + ps) - kt[2])) + p2;
-        if (logP != logP) logP = -__builtin_huge_val();
-        return logP;
-    }
-
     template <bool SORTED>
     static RMH_DEV double log_lik(const double *xy, const CpRjArgs &m, const State &s, int g)
     {
@@ -1073,6 +1032,145 @@ struct CpRj {
         double logL = -0.5 * ((ss + b.n * log_full(sig2)) + b.nlog2pi);
         if (logL != logL) logL = -__builtin_huge_val();
         return logL;
+    }
+
+    // log_prior for k changepoints (k' = k + 1 pieces), changepoint.py:128-160, with the lane walking all
+    // pieces itself, in order.  sum_j log(ds_j) = log(prod_j ds_j), guarded by min_j ds_j > 0 (two
+    // negative gaps must not cancel), as in k_cp_rw_ss: one logarithm instead of k + 1; pieces beyond k
+    // contribute a factor 1.  alpha = 1: (alpha - 1) log(v) is +-0 for 0 < v < inf and NaN otherwise,
+    // exactly as numpy evaluates it -- no logarithm per height either.  ONE statement for the four-lane
+    // kernel (every lane of a chain evaluates it: the state is replicated there), the one-lane kernel and
+    // the evaluation entry: a shard that runs on one kernel and the whole job that runs on the other must
+    // agree bit for bit (round 2's four-lane version split the pieces over the chain's lanes, four
+    // logarithms per lane and a sum across lanes).
+    static RMH_DEV double log_prior1(const CpRjArgs &m, const double *ktab, const State &s, int KM)
+    {
+        const CpArgs &b = m.base;
+        double pv = 0.0, prod = 1.0, dmin = __builtin_huge_val();
+        bool vbad = false;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            if (j <= KM) { // (wave-uniform: the model's capacity)
+                const bool valid = j <= s.k;
+                const double lo = (j == 0) ? b.xmin : s.cpx[j >= 1 ? j - 1 : 0];
+                double hi = (j < KD) ? s.cpx[j < KD ? j : 0] : b.xmax;
+                hi = (j == s.k) ? b.xmax : hi;        // the last piece ends at xmax (cpx beyond k is +inf)
+                const double dx = valid ? hi - lo : 1.0, vv = valid ? s.cpv[j] : 1.0;
+                prod *= dx;
+                dmin = __builtin_fmin(dmin, dx);      // (a NaN gap leaves dmin alone and poisons prod)
+                double la = 0.0;
+                if (b.alpha_m1 == 0.0) vbad = vbad || !(vv > 0.0 && vv < __builtin_huge_val());
+                else la = b.alpha_m1 * log_full(vv);
+                const double tv = ((b.c_v + la) - b.beta * vv) - b.lgam_alpha;
+                pv += valid ? tv : 0.0;
+            }
+        }
+        const double nan = __builtin_nan("");
+        const double sig2 = s.sig * s.sig;
+        double lprod, lsig2;
+        {
+            double dummy;
+            log_fast3(prod, sig2, 1.0, lprod, lsig2, dummy);
+        }
+        const double ps = (dmin > 0.0) ? lprod : (dmin == 0.0 ? -__builtin_huge_val() : nan);
+        if (vbad) pv = nan;
+        const double *kt = ktab + 4 * (s.k + 1);
+        const double p2 = (s.sig < 0.0) ? nan : -lsig2;          // log(1 / sig^2)
+        double logP = ((kt[0] + pv) + ((kt[1] + ps) - kt[2])) + p2;
+        if (logP != logP) logP = -__builtin_huge_val();
+        return logP;
+    }
+
+    // ---- one lane per chain (k_cprj_run64) --------------------------------------------------------
+    // the likelihood from sufficient statistics, all boundary searches by this lane, step by step side
+    // by side (independent chains of dependent LDS reads: the wave's only latency cover); the pieces are
+    // summed exactly as log_lik_ss sums them
+    // S2 > 0: the bucket table of k_cp_rw_ss64 in front of the searches (CpArgs::ss_nb): one multiply-and-
+    // truncate and one table read, then S2 search steps -- 1 + S2 dependent LDS round trips per boundary
+    // instead of floor(log2 n) + 1.  Same counts, hence the same bits.
+    template <int STEPS, int S2>
+    static RMH_DEV double log_lik_ss1(const double *xs, const double *P1, const int32_t *bk, const CpRjArgs &m,
+                                      const State &s, int KM)
+    {
+        const CpArgs &b = m.base;
+        int lo8[KD];
+#pragma unroll
+        for (int j = 0; j < KD; ++j) lo8[j] = 0;
+        if (S2 > 0) {
+            const double nbm1 = (double)(b.ss_nb - 1);
+#pragma unroll
+            for (int j = 0; j < KD; ++j)
+                if (j < KM) {
+                    // (+inf beyond k: the product clamps to the last bucket, the steps run into the +inf padding)
+                    const double fb = __builtin_fmin(__builtin_fmax((s.cpx[j] - b.ss_x0) * b.ss_invh, 0.0), nbm1);
+                    lo8[j] = bk[(int)fb];                         // 8 L[bucket]
+                }
+#pragma unroll
+            for (int sp = S2 - 1; sp >= 0; --sp)
+#pragma unroll
+                for (int j = 0; j < KD; ++j)
+                    if (j < KM) {
+                        const double xv = *reinterpret_cast<const double *>(
+                            reinterpret_cast<const char *>(xs) + lo8[j] + ((8 << sp) - 8));
+                        lo8[j] += (xv <= s.cpx[j]) ? (8 << sp) : 0;
+                    }
+        } else if (STEPS > 0) {
+#pragma unroll
+            for (int st = STEPS - 1; st >= 0; --st)
+#pragma unroll
+                for (int j = 0; j < KD; ++j)
+                    if (j < KM) {
+                        const double xv = *reinterpret_cast<const double *>(
+                            reinterpret_cast<const char *>(xs) + lo8[j] + ((8 << st) - 8));
+                        lo8[j] += (xv <= s.cpx[j]) ? (8 << st) : 0;
+                    }
+        } else {
+            for (int st = b.ss_steps - 1; st >= 0; --st) {
+                const int step8 = 8 << st;
+#pragma unroll
+                for (int j = 0; j < KD; ++j)
+                    if (j < KM) {
+                        const double xv = *reinterpret_cast<const double *>(
+                            reinterpret_cast<const char *>(xs) + lo8[j] + step8 - 8);
+                        lo8[j] += (xv <= s.cpx[j]) ? step8 : 0;
+                    }
+            }
+        }
+        const double bn = (double)b.n, pn = P1[b.n];
+        double acc = 0.0, bprev = 0.0, pprev = 0.0;
+#pragma unroll
+        for (int pz = 0; pz < KP; ++pz) {
+            // (all KP pieces, as log_lik_ss: beyond the capacity cpv is 1 and the run is empty)
+            double bcur = bn, pcur = pn;
+            if (pz < KD) {
+                const int b8 = lo8[pz < KD ? pz : 0];
+                const bool in = pz < s.k;   // boundaries from k on are clamped to (n, P1[n]): the pieces beyond k are empty
+                bcur = in ? (double)(b8 >> 3) : bn;
+                pcur = in ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(P1) + (in ? b8 : 0)) : pn;
+            }
+            const double vc = s.cpv[pz] - b.ss_ym;
+            acc = fma_(vc, fma_(bcur - bprev, vc, -2.0 * (pcur - pprev)), acc);
+            bprev = bcur;
+            pprev = pcur;
+        }
+        const double sig2 = s.sig * s.sig;
+        const double ss = (b.ss_p2 + acc) / sig2;
+        double logL = -0.5 * ((ss + b.n * log_full(sig2)) + b.nlog2pi);
+        if (logL != logL) logL = -__builtin_huge_val();
+        return logL;
+    }
+
+    // all rows of the padded layout by this lane (64 consecutive chains per instruction)
+    static RMH_DEV void store1(double *dst, int64_t ld, int64_t c, int KM, const State &s)
+    {
+#pragma unroll
+        for (int j = 0; j < KD; ++j)
+            if (j < KM) dst[(int64_t)j * ld + c] = s.cpx[j];
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+            if (j <= KM) dst[(int64_t)(KM + j) * ld + c] = s.cpv[j];
+        dst[(int64_t)(2 * KM + 1) * ld + c] = s.sig;
+        dst[(int64_t)(2 * KM + 2) * ld + c] = (double)s.k;
     }
 
     static RMH_DEV void load(const double *theta, int64_t ld, int64_t c, int KM, State &s)
@@ -1226,7 +1324,7 @@ __global__ void __launch_bounds__(256, (KD <= 6 ? 3 : 2)) k_cprj_run(CpRjArgs m,
         }
         double lpp = -__builtin_huge_val();
         if (mv != 5) {
-            const double logP = R::log_prior(m, ktab, tp, g);
+            const double logP = R::log_prior1(m, ktab, tp, KM);
             if (__any(logP > -__builtin_huge_val())) {
                 const double logL = SS >= 0 ? R::template log_lik_ss<SS>(xy, xy + np, brow, m, tp, g)
                                             : R::template log_lik<true>(xy, m, tp, g);
@@ -1245,6 +1343,199 @@ __global__ void __launch_bounds__(256, (KD <= 6 ? 3 : 2)) k_cprj_run(CpRjArgs m,
     R::store(ch.theta, ch.ld, c, KM, g, th);
     if (g == 0) ch.logpost[c] = lp;
     xo_store(ch.rng, ch.nslots, slot, rng);
+}
+
+// ---- the trans-dimensional sampler with ONE lane per chain (round 3) --------------------------
+// k_cprj_run keeps a chain in four lanes and replicates the move logic -- five divergent branches that
+// rebuild the padded state through static-index selects -- in all of them.  Only the draws need four
+// lanes per chain (the stream's four sub-streams).  As k_cp_rw_ss64: a wavefront owns 64 chains, draws in
+// four passes of 16 chains x 4 sub-streams (normals of the 2 KM + 2 padded coordinates, then the two
+// uniform words of every sub-stream), parks them in an LDS row per chain, and lane l alone carries chain l
+// through the move, the prior, the KM boundary searches, the likelihood, the accept test and the record.
+// Same stream, same moves, same accept rule, the same arithmetic as the four-lane kernel (CpRj::
+// log_prior1 is shared, log_lik_ss1 sums the pieces as log_lik_ss does): a shard on one kernel equals
+// those chains of a job on the other bit for bit.
+template <int KD, int SS, int S2 = 0>
+__global__ void __launch_bounds__(256) k_cprj_run64(CpRjArgs m, ChainArgs ch, RunArgs run)
+{
+    using R = CpRj<KD>;
+    constexpr int KP = KD + 1;
+    static_assert(SS >= 0, "sufficient statistics only");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int KM = m.KM, Dn = 2 * KM + 2, n = m.base.n;
+    const int np = (1 << m.base.ss_steps) - 1;
+    const int TS = 2 * (((Dn + 9) / 2) | 1);       // row: Dn normals + 8 uniforms, an odd number of 16-byte units
+    const int bkd = S2 > 0 ? (((m.base.ss_nb + 2) / 2 + 1) & ~1) : 0;   // doubles of the bucket table (int32 entries)
+    double *xs = lds, *P1 = lds + np;
+    const int32_t *bk = reinterpret_cast<const int32_t *>(lds + 2 * np + 2);
+    double *ktab = lds + 2 * np + 2 + bkd;         // (KM+2) x 4
+    double *tab = ktab + 4 * (KM + 2);
+    double *xch = tab + kIcdfDoubles;              // per wave: 64 rows of TS doubles
+    for (int i = threadIdx.x; i < 2 * np + 1; i += blockDim.x) lds[i] = m.base.ss_xp[i];
+    if (S2 > 0)
+        for (int i = threadIdx.x; i < (m.base.ss_nb + 2) / 2; i += blockDim.x)
+            lds[2 * np + 2 + i] = m.base.ss_xp[2 * np + 2 + i];
+    for (int i = threadIdx.x; i < 4 * (KM + 2); i += blockDim.x) ktab[i] = m.ktab[i];
+    icdf_stage(tab, ch.icdf);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 15, g = lane >> 4;
+    const int64_t grp = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;   // group of 64 chains
+    const int64_t blk0 = grp * 4;
+    if (blk0 >= ch.nblocks) return;
+    double *rows = xch + wave * (64 * TS);
+    const double *xw = rows + lane * TS;           // this lane's chain: normals by coordinate, then the uniforms
+    const int64_t c = grp * 64 + lane;
+    const bool live = c < ch.ld;
+    const int64_t cs = live ? c : ch.ld - 1;       // (a lane beyond the padded chains shadows the last one)
+
+    typename R::State th;
+    R::load(ch.theta, ch.ld, cs, KM, th);
+    double lp = ch.logpost[cs];
+    Xo st[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int64_t slot = ((blk0 + b < ch.nblocks) ? blk0 + b : blk0) * 64 + lane;
+        st[b] = xo_load(ch.rng, ch.nslots, slot);
+    }
+    const int rowsH = 4 * ch.ks;
+
+    int64_t knext = run.nburn, kentry = 0;
+    auto rec = [&](int64_t e) {
+        if (e != knext) return;
+        knext += run.nthin;
+        const int64_t kk = kentry++;
+        if (!run.h_theta || !live) return;
+        R::store1(run.h_theta + kk * (int64_t)rowsH * ch.ld, ch.ld, c, KM, th);
+        run.h_logpost[kk * ch.ld + c] = lp;
+    };
+    rec(0);
+
+    const int MW = (Dn + 7) / 8;
+    for (int64_t t = 0; t < run.T; ++t) {
+        asm volatile("" ::: "memory");
+        // ---- the draws: pass b = chains 16 b + cl of the group, sub-stream g.  One wave per SIMD has
+        // nobody to hide latencies behind: the four passes' xoshiro steps of a word side by side, the
+        // normals of two passes (four half words) in lockstep
+        double *row0 = rows + cl * TS;
+        for (int mm = 0; mm < MW; ++mm) {
+            uint64_t w[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) w[b] = xo_next(st[b]);
+            const bool hi_in = 8 * mm + g < Dn, lo_in = 8 * mm + 4 + g < Dn;
+#pragma unroll
+            for (int b0 = 0; b0 < 4; b0 += 2) {
+                const uint32_t hw[4] = {(uint32_t)(w[b0] >> 32), (uint32_t)w[b0], (uint32_t)(w[b0 + 1] >> 32),
+                                        (uint32_t)w[b0 + 1]};
+                double zw[4];
+                normals_lockstep<4>(hw, tab, zw);
+                double *ra = row0 + 16 * b0 * TS + 8 * mm + g, *rb = ra + 16 * TS;
+                if (hi_in) {
+                    ra[0] = zw[0];
+                    rb[0] = zw[2];
+                }
+                if (lo_in) {
+                    ra[4] = zw[1];
+                    rb[4] = zw[3];
+                }
+            }
+        }
+        {
+            double u1[4], u2[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) u1[b] = u01(xo_next(st[b]));       // (accept, U1, U2, U3)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) u2[b] = u01(xo_next(st[b]));       // (U4, location, height split, index)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                row0[16 * b * TS + Dn + g] = u1[b];
+                row0[16 * b * TS + Dn + 4 + g] = u2[b];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes are in order
+        const double uacc = xw[Dn], U1 = xw[Dn + 1], U2 = xw[Dn + 2], U3 = xw[Dn + 3];
+        const double U4 = xw[Dn + 4], us = xw[Dn + 5], uu = xw[Dn + 6], un = xw[Dn + 7];
+
+        typename R::State tp = th;
+        double logq = 0.0;
+        int mv;
+        const int k = th.k;
+        if (U1 < m.pcum[0]) { // cpx block, test_changepoint.py:47-49
+            mv = 0;
+            const double sx = ktab[4 * (k + 1) + 3];
+#pragma unroll
+            for (int j = 0; j < KD; ++j)
+                if (j < KM) tp.cpx[j] = (j < k) ? th.cpx[j] + sx * xw[j] : th.cpx[j];
+        } else if (U2 < m.pcum[1]) { // cpv block, :50-52
+            mv = 1;
+#pragma unroll
+            for (int j = 0; j < KP; ++j)
+                if (j <= KM) tp.cpv[j] = (j <= k) ? th.cpv[j] + m.sv * xw[KM + j] : th.cpv[j];
+        } else if (U3 < m.pcum[2]) { // sig, :53-55
+            mv = 2;
+            tp.sig = th.sig + m.ss * xw[2 * KM + 1];
+        } else if (k == 0 || U4 > 0.5) { // birth, :58-63, changepoint.py:193-218
+            mv = 3;
+            const double s = m.base.xmin + (m.base.xmax - m.base.xmin) * us;
+            const double u = 0.5 + (-0.1 + 0.2 * uu) / sqrt((double)n);
+            if (k >= KM) {
+                mv = 5; // no room: refused
+            } else {
+                int nn = 0;
+#pragma unroll
+                for (int j = 0; j < KD; ++j) nn += (th.cpx[j] < s) ? 1 : 0; // +inf beyond k
+                const double h = R::sel(th.cpv, nn), ufac = sqrt((1.0 - u) / u);
+                const double h1 = h / ufac, h2 = h * ufac;
+#pragma unroll
+                for (int j = 0; j < KD; ++j)
+                    tp.cpx[j] = (j < nn) ? th.cpx[j] : (j == nn) ? s : th.cpx[j > 0 ? j - 1 : 0];
+#pragma unroll
+                for (int j = 0; j < KP; ++j)
+                    tp.cpv[j] = (j < nn) ? th.cpv[j] : (j == nn) ? h1 : (j == nn + 1) ? h2 : th.cpv[j > 0 ? j - 1 : 0];
+                tp.k = k + 1;
+                logq = log_full(__builtin_fabs(h / (u * (1.0 - u))));
+            }
+        } else { // death, :65-71, changepoint.py:220-240
+            mv = 4;
+            int nn = (int)(un * k);
+            nn = nn >= k ? k - 1 : nn;
+            const double h1 = R::sel(th.cpv, nn), h2 = R::sel(th.cpv, nn + 1);
+            const double h = sqrt(h1 * h2), u = 1.0 / (1.0 + h2 / h1);
+#pragma unroll
+            for (int j = 0; j < KD; ++j)
+                tp.cpx[j] = (j < nn) ? th.cpx[j] : (j + 1 < KD ? th.cpx[j + 1 < KD ? j + 1 : 0] : __builtin_huge_val());
+#pragma unroll
+            for (int j = 0; j < KP; ++j)
+                tp.cpv[j] = (j < nn) ? th.cpv[j] : (j == nn) ? h : (j + 1 < KP ? th.cpv[j + 1 < KP ? j + 1 : 0] : 1.0);
+            tp.k = k - 1;
+            logq = log_full(__builtin_fabs(u * (1.0 - u) / h));
+        }
+        double lpp = -__builtin_huge_val();
+        double logP = -__builtin_huge_val();
+        if (mv != 5) logP = R::log_prior1(m, ktab, tp, KM);
+        if (__any(logP > -__builtin_huge_val())) {
+            const double logL = R::template log_lik_ss1<SS, S2>(xs, P1, bk, m, tp, KM);
+            lpp = combine_post(logP, logL);
+        }
+        const bool ok = mh_accept(lpp, lp, logq, uacc);
+        if (ok) {
+            th = tp;
+            lp = lpp;
+        }
+        // accept byte: bit 0 accepted, bits 1..3 the move (0 cpx, 1 cpv, 2 sig, 3 birth, 4 death, 5 refused)
+        if (run.h_accept && live) run.h_accept[t * ch.ld + c] = (uint8_t)((ok ? 1 : 0) | (mv << 1));
+        rec(t + 1);
+        __builtin_amdgcn_wave_barrier();                      // the rows are rewritten by the next draws
+    }
+    if (live) {
+        R::store1(ch.theta, ch.ld, c, KM, th);
+        ch.logpost[c] = lp;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        if (blk0 + b < ch.nblocks) xo_store(ch.rng, ch.nslots, (blk0 + b) * 64 + lane, st[b]);
 }
 
 template <int KD>
@@ -1266,7 +1557,7 @@ __global__ void __launch_bounds__(256) k_cprj_eval(CpRjArgs m, ChainArgs ch, dou
     typename R::State th;
     R::load(ch.theta, ch.ld, c, KM, th);
     th.k = th.k < 0 ? 0 : th.k > KM ? KM : th.k;
-    const double logP = R::log_prior(m, ktab, th, g);
+    const double logP = R::log_prior1(m, ktab, th, KM);
     const double logL = R::template log_lik<false>(xy, m, th, g);
     if (g == 0) {
         if (lprior) lprior[c] = logP;
@@ -1281,6 +1572,37 @@ hipError_t launch_cprj_run(const CpRjArgs &m, const ChainArgs &c, const RunArgs 
     // keeps the O(n k) loop over the data (measurements, cross-checks)
     const bool ss = m.base.ss_xp && !policy(RMH_POLICY_CPRJ_NO_SS);
     const int np = (1 << m.base.ss_steps) - 1;
+    // one lane per chain once every SIMD of the chip gets a wavefront of 64 chains (as k_cp_rw_ss64)
+    if (ss && m.KM <= 14 && (policy(RMH_POLICY_CP_SS64) || (c.nblocks >= 4096 && !policy(RMH_POLICY_CP_SS16)))) {
+        const int Dn = 2 * m.KM + 2, TS = 2 * (((Dn + 9) / 2) | 1), nw = 4;
+        const bool buckets = m.base.ss_nb > 0 && (m.base.ss_s2 == 2 || m.base.ss_s2 == 3) && !policy(RMH_POLICY_CP_NO_BUCKETS);
+        const size_t bkd = buckets ? (size_t)(((m.base.ss_nb + 2) / 2 + 1) & ~1) : 0;
+        const size_t lds64 = sizeof(double) * ((size_t)2 * np + 2 + bkd + 4 * (m.KM + 2) + kIcdfDoubles + (size_t)nw * 64 * TS);
+        if (lds64 <= 160 * 1024) {
+            const int64_t ngrp = (c.nblocks + 3) / 4;
+            const dim3 grid64((unsigned)((ngrp + nw - 1) / nw));
+#define RMH_CPRJ64(...)                                                                                   \
+    {                                                                                                     \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cprj_run64<__VA_ARGS__>),     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);       \
+        if (e != hipSuccess) return e;                                                                    \
+        hipLaunchKernelGGL((k_cprj_run64<__VA_ARGS__>), grid64, dim3(64 * nw), lds64, st, m, c, r);       \
+        return hipGetLastError();                                                                         \
+    }
+#define RMH_CPRJ64_KD(KD)                                         \
+    {                                                             \
+        if (buckets && m.base.ss_s2 == 2) RMH_CPRJ64(KD, 0, 2)    \
+        if (buckets && m.base.ss_s2 == 3) RMH_CPRJ64(KD, 0, 3)    \
+        if (m.base.ss_steps == 7) RMH_CPRJ64(KD, 7, 0)            \
+        RMH_CPRJ64(KD, 0, 0)                                      \
+    }
+            if (m.KM <= 6) RMH_CPRJ64_KD(6)
+            if (m.KM <= 10) RMH_CPRJ64_KD(10)   // the reference script's capacity, 2 Ncpx = 10 (test_changepoint.py)
+            RMH_CPRJ64_KD(14)
+#undef RMH_CPRJ64_KD
+#undef RMH_CPRJ64
+        }
+    }
     const size_t ndata = ss ? (size_t)2 * np + 2 : (size_t)2 * m.base.n;
     const size_t lds = sizeof(double) * (ndata + 4 * (m.KM + 2) + kIcdfDoubles + 4 * 16 * 32 +
                                          (ss ? 4 * 16 * 2 * (14 | 1) : 0));

@@ -165,9 +165,12 @@ def test_changepoint_with_the_generic_kernels_vs_oracle(ra, orc):
     np.testing.assert_allclose(pt._host_thetas, ht[:, idx], rtol=RTOL, atol=1e-12)
 
 
-def test_g17_trans_dimensional_changepoint_sampler_vs_reference_fixture(ra):
+@pytest.mark.parametrize("policy", [(), ("CP_SS64",)])
+def test_g17_trans_dimensional_changepoint_sampler_vs_reference_fixture(ra, policy):
     """The reference's ChangepointRegression1DProp with its birth/death branch: moves, accepts,
-    the number of changepoints and the states of 4 chains x 300 iterations."""
+    the number of changepoints and the states of 4 chains x 300 iterations.  policy CP_SS64: the
+    one-lane-per-chain kernel k_cprj_run64, which takes over by itself from 65 536 chains."""
+    from riemann_amd._lib import kernel_policy
     from riemann_amd.proposals import ChangepointRegression1DProp
     z = load("g17_changepoint_rj")
     m = rj_model(z)
@@ -177,8 +180,9 @@ def test_g17_trans_dimensional_changepoint_sampler_vs_reference_fixture(ra):
     p = ChangepointRegression1DProp(m, float(z["hscale"]))
     assert p.P_cumprop_dim == 1.0
     p.P_cumprop_sig = 0.0                    # as the fixture (the reference's sig block raises under numpy 2)
-    s = ra.Sampler(m, p, start, seed=int(z["seed"]))
-    s.run(300)
+    with kernel_policy(*policy):
+        s = ra.Sampler(m, p, start, seed=int(z["seed"]))
+        s.run(300)
     code = s._chain_accept
     mv = code >> 1          # a birth at k = kmax is "refused" (5) where the reference proposes (3) and rejects
     np.testing.assert_array_equal(np.where(mv == 5, 3, mv), z["move"])
@@ -193,9 +197,11 @@ def test_g17_trans_dimensional_changepoint_sampler_vs_reference_fixture(ra):
     assert [len(t.cpx) for t in last] == list(z["thetas"][-1, :, -1].astype(int))
 
 
-@pytest.mark.parametrize("KM,N", [(5, 3000), (12, 1000)])
-def test_trans_dimensional_changepoint_many_chains_vs_oracle(ra, orc, KM, N):
+@pytest.mark.parametrize("KM,N,policy", [(5, 3000, ()), (12, 1000, ()), (5, 3001, ("CP_SS64",)), (12, 1000, ("CP_SS64",)),
+                                         (10, 2100, ("CP_SS64",)), (10, 700, ("CP_SS64", "CP_NO_BUCKETS"))])
+def test_trans_dimensional_changepoint_many_chains_vs_oracle(ra, orc, KM, N, policy):
     """Default probabilities (all five move types, births refused at capacity) on many chains."""
+    from riemann_amd._lib import kernel_policy
     from riemann_amd import workloads as W
     from riemann_amd.models import ChangepointRegression1D
     from riemann_amd.proposals import ChangepointRegression1DProp
@@ -209,9 +215,10 @@ def test_trans_dimensional_changepoint_many_chains_vs_oracle(ra, orc, KM, N):
         starts.append((np.sort(g.uniform(1.05, 2.95, size=k)), g.uniform(1.0, 3.0, size=k + 1), float(g.uniform(0.2, 1.0))))
     th0 = orc.cprj_pack(starts, KM)
     p = ChangepointRegression1DProp(m, 2.0)
-    s = ra.Sampler(m, p, th0, seed=6, chain0=160)
     T = 80
-    s.run(T)
+    with kernel_policy(*policy):
+        s = ra.Sampler(m, p, th0, seed=6, chain0=160)
+        s.run(T)
     th = th0.copy()
     lp = orc.cprj_log_posterior(om, KM, th)
     ht, hl, acc, mv = orc.run_cprj(om, KM, 2.0, [0.2, 0.4, 0.6], th, lp, orc.rng_seed(6, N, chain0=160), T)

@@ -5,6 +5,8 @@
 """
 import sys
 
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import riemann_amd as ra
 from riemann_amd import workloads as W
 from riemann_amd.models import ChangepointParams, ChangepointRegression1D

@@ -72,11 +72,14 @@ std::vector<double> pack_upper_T(const double *M, int d, int NT)
 // TailAcc): [group S of four k-steps][lane group g][4 q + r] = M[96 + r][4 (4S + q) + g]
 std::vector<double> pack_tail(const double *M, int d, double scale)
 {
-    std::vector<double> t((size_t)7 * 64, 0.0);
-    for (int s = 0; s < 25; ++s)
+    // d = 16 NF + 1 .. 16 NF + 4: rows 16 NF .. of a lower-triangular matrix, [S][g][4 q + r] =
+    // scale * M[16 NF + r][4 (4 S + q) + g] for the k-steps s = 4 S + q <= 4 NF (TailAcc, rmh_run.hpp)
+    const int NF = (d - 1) / 16, r0 = 16 * NF;
+    std::vector<double> t((size_t)(NF + 1) * 64, 0.0);
+    for (int s = 0; s <= 4 * NF; ++s)
         for (int g = 0; g < 4; ++g)
             for (int r = 0; r < 4; ++r) {
-                const int row = 96 + r, col = 4 * s + g;
+                const int row = r0 + r, col = 4 * s + g;
                 if (row < d && col < d && col <= row)
                     t[(size_t)((s / 4) * 4 + g) * 16 + 4 * (s % 4) + r] = scale * M[(size_t)row * d + col];
             }

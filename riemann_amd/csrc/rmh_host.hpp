@@ -145,9 +145,10 @@ int64_t pad16(int64_t n);
 std::vector<double> pack_lower(const double *M, int d, int NT, double scale);
 std::vector<double> pack_upper_T(const double *M, int d, int NT);
 bool lower_ok(const double *L, int d);
-// rows 96..99 of a lower-triangular (d, d) matrix, [s][g][r] = scale * M[96 + r][4s + g] (25 x 4 x 4)
+// d = 16 NF + 1 .. 16 NF + 4: rows 16 NF .. of a lower-triangular (d, d) matrix in the layout of TailAcc (rmh_run.hpp)
 std::vector<double> pack_tail(const double *M, int d, double scale);
-inline bool has_tail(int d) { return d >= 97 && d <= 100; }
+// the last row tile holds at most four rows: they run on the VALU (k_run_rw_tail), d = 17..20, 33..36, ... 97..100
+inline bool has_tail(int d) { return d > 16 && d <= 100 && (d - 1) % 16 < 4; }
 bool cholesky_lower(const std::vector<double> &Cm, int d, std::vector<double> &L);
 
 ChainArgs chain_args(const rmh_state *s);

@@ -39,20 +39,41 @@ hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const Ch
     })
 }
 
-// d = 97..100, random walk (plain, per-chain adapted scale, or within parallel tempering when
-// r.pt_K > 0): rows 96..99 on the VALU (k_run_rw_tail)
+// d = 16 NF + 1 .. 16 NF + 4, random walk (plain, per-chain adapted scale, or within parallel tempering
+// when r.pt_K > 0): the NF full row tiles on the matrix core, the four tail rows on the VALU
+// (k_run_rw_tail); r.mom_partial: the AdaptCov variant with the pooled moments in the kernel (NF = 6)
+template <int NF>
+static hipError_t gauss_rw_tail_launch(const GaussArgs &m, const RwArgs &p, const ChainArgs &c, const RunArgs &r,
+                                       bool adapt, hipStream_t st)
+{
+    // as the generic kernels: eight waves once the tile images fill most of a CU's LDS
+    constexpr int NW = (NF >= 4) ? 8 : 4;
+    const size_t lds = sizeof(double) * (2 * tri_tiles(NF) * 64 + 2 * tail_doubles(NF) + 4 * 4 * (NF + 1) + kIcdfDoubles);
+    if (r.mom_partial) { // AdaptCov: the pooled moments of the states 1..T accumulated in the kernel
+        if constexpr (NF == 6) {
+            if (r.pt_K > 0 || adapt) return hipErrorInvalidValue;
+            return launch(k_run_rw_tail<6, 8, false, false, true>, c.nblocks, 8, lds + sizeof(double) * 2 * kMomPanel,
+                          st, m, p, c, r);
+        }
+        return hipErrorInvalidValue;
+    }
+    if (r.pt_K > 0) return launch(k_run_rw_tail<NF, NW, false, true>, c.nblocks, NW, lds, st, m, p, c, r);
+    if (adapt) return launch(k_run_rw_tail<NF, NW, true, false>, c.nblocks, NW, lds, st, m, p, c, r);
+    return launch(k_run_rw_tail<NF, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);
+}
+
 hipError_t launch_gauss_rw_tail(const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                                 const RunArgs &r, bool adapt, hipStream_t st)
 {
-    const size_t lds = sizeof(double) * (2 * tri_tiles(6) * 64 + 2 * kTailDoubles + 4 * 28 + kIcdfDoubles);
-    if (r.mom_partial) { // AdaptCov: the pooled moments of the states 1..T accumulated in the kernel
-        if (r.pt_K > 0 || adapt) return hipErrorInvalidValue;
-        return launch(k_run_rw_tail<8, false, false, true>, c.nblocks, 8, lds + sizeof(double) * 2 * kMomPanel, st,
-                      m, p, c, r);
+    switch ((c.d - 1) / 16) {   // NF full row tiles
+    case 1: return gauss_rw_tail_launch<1>(m, p, c, r, adapt, st);
+    case 2: return gauss_rw_tail_launch<2>(m, p, c, r, adapt, st);
+    case 3: return gauss_rw_tail_launch<3>(m, p, c, r, adapt, st);
+    case 4: return gauss_rw_tail_launch<4>(m, p, c, r, adapt, st);
+    case 5: return gauss_rw_tail_launch<5>(m, p, c, r, adapt, st);
+    case 6: return gauss_rw_tail_launch<6>(m, p, c, r, adapt, st);
+    default: return hipErrorInvalidValue;
     }
-    if (r.pt_K > 0) return launch(k_run_rw_tail<8, false, true>, c.nblocks, 8, lds, st, m, p, c, r);
-    if (adapt) return launch(k_run_rw_tail<8, true, false>, c.nblocks, 8, lds, st, m, p, c, r);
-    return launch(k_run_rw_tail<8, false, false>, c.nblocks, 8, lds, st, m, p, c, r);
 }
 
 int64_t gauss_rw_tail_workgroups(int64_t nblocks) { return (nblocks + 7) / 8; }
@@ -404,14 +425,16 @@ __global__ void __launch_bounds__(1024) k_acov_update(AcovUpdateArgs a)
         if (row < d && col < d && col <= row) v = A[row * ds + col];
         a.Limg[idx] = a.img_scale * v;
     }
-    // rows 96.. for the VALU tail of k_run_rw_tail (d = 97..100), layout of pack_tail (rmh_api.hip)
+    // the four tail rows 16 NF .. for the VALU tail of k_run_rw_tail (d = 16 NF + 1 .. + 4), layout of
+    // pack_tail (rmh_api.hip)
     if (a.Ltail) {
-        for (int idx = tid; idx < 7 * 64; idx += nth) {
+        const int NFt = (d - 1) / 16, r0 = 16 * NFt;
+        for (int idx = tid; idx < (NFt + 1) * 64; idx += nth) {
             const int G = idx >> 6, g = (idx >> 4) & 3, e = idx & 15;   // [(G*4 + g)*16 + 4 q + r]
             const int sg = 4 * G + (e >> 2), r = e & 3;
-            const int row = 96 + r, col = 4 * sg + g;
+            const int row = r0 + r, col = 4 * sg + g;
             double v = 0.0;
-            if (sg < 25 && row < d && col < d && col <= row) v = a.img_scale * A[row * ds + col];
+            if (sg <= 4 * NFt && row < d && col < d && col <= row) v = a.img_scale * A[row * ds + col];
             a.Ltail[idx] = v;
         }
     }

@@ -303,11 +303,17 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
 // (2 ds_read_b128, the first version) moved 16x the bytes: those reads cost 2.0 of 34.8 ms.
 // The DPP source must not have been written by the VALU in the two preceding wait states; the
 // compiler does not see inside the asm, tools/check_dpp_hazards.py (a CPU test) checks the build.
-constexpr int kTailS = 25, kTailGroups = 7, kTailDoubles = kTailGroups * 64;
+// Round 3: the same for every d = 16 NF + 1 .. 16 NF + 4 (NF = 1..6 full row tiles): NF as a template
+// parameter of the tail pieces and of the kernel -- d = 36 no longer pays a whole padded row tile.
+constexpr int tail_ksteps(int NF) { return 4 * NF + 1; }   // k-steps 0 .. 4 NF carry coordinates
+constexpr int tail_doubles(int NF) { return (NF + 1) * 64; }
+constexpr int kTailDoubles = tail_doubles(6);
 
+template <int NF>
 struct TailAcc {
+    static constexpr int kS = tail_ksteps(NF), kG = NF + 1;
     double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-    double c[kTailGroups];
+    double c[kG];
     // this lane's entry of group S (lt: the image, g/cl: lane group and lane in the row)
     RMH_DEV void load(const double *lt, int g, int cl, int S) { c[S] = lt[(S * 4 + g) * 16 + cl]; }
     // the four rows' FMAs of k-step s = 4 S + Q
@@ -319,62 +325,87 @@ struct TailAcc {
         fmac_bcast<4 * Q + 2>(t2, c[S], x);
         fmac_bcast<4 * Q + 3>(t3, c[S], x);
     }
-    // k-steps 4S .. 4S+3 (the last group holds k-step 24 only)
+    // k-steps 4S .. 4S+3 (the last group holds k-step 4 NF only)
     template <int S>
-    RMH_DEV void group(const double (&v)[28])
+    RMH_DEV void group(const double (&v)[4 * (NF + 1)])
     {
         step<S, 0>(v[4 * S]);
-        if (4 * S + 1 < kTailS) {
+        if (4 * S + 1 < kS) {
             step<S, 1>(v[4 * S + 1]);
             step<S, 2>(v[4 * S + 2]);
             step<S, 3>(v[4 * S + 3]);
+        }
+    }
+    template <int S0>
+    RMH_DEV void groups_from(const double (&v)[4 * (NF + 1)])
+    {
+        if constexpr (S0 < kG) {
+            group<S0>(v);
+            groups_from<S0 + 1>(v);
         }
     }
     // row g of the result on lane group g
     RMH_DEV double finish() { return sum4_scatter(t0, t1, t2, t3); }
 };
 
-RMH_DEV double tail_rows(const double *lt, int g, int cl, const double (&v)[28])
+template <int NF>
+RMH_DEV double tail_rows(const double *lt, int g, int cl, const double (&v)[4 * (NF + 1)])
 {
-    TailAcc tl;
+    TailAcc<NF> tl;
 #pragma unroll
-    for (int S = 0; S < kTailGroups; ++S) tl.load(lt, g, cl, S);
-    tl.group<0>(v);
-    tl.group<1>(v);
-    tl.group<2>(v);
-    tl.group<3>(v);
-    tl.group<4>(v);
-    tl.group<5>(v);
-    tl.group<6>(v);
+    for (int S = 0; S < NF + 1; ++S) tl.load(lt, g, cl, S);
+    tl.template groups_from<0>(v);
     return tl.finish();
 }
 
-// log N(theta | mu, C) from y = theta - mu for d = 97..100: |W y|^2 with row tiles 0..5 on the
-// matrix core (two in flight) and rows 96..99 on the VALU
+// log N(theta | mu, C) from y = theta - mu for d = 16 NF + 1 .. 16 NF + 4: |W y|^2 with the NF full row
+// tiles on the matrix core (two in flight) and the four tail rows on the VALU
+template <int NF>
 RMH_DEV double gauss_loglik(const double *Wimg, const double *Wt, const GaussArgs &m, int lane, int g,
-                            int cl, const double (&y)[28])
+                            int cl, const double (&y)[4 * (NF + 1)])
 {
-    using T = Tile<7>;
-    constexpr int NF = 6;
+    using T = Tile<NF + 1>;
     double uu = 0.0;
 #pragma unroll
     for (int i0 = 0; i0 < NF; i0 += 2) {
         double4_t a0 = double4_t{0.0, 0.0, 0.0, 0.0}, a1 = a0;
+        constexpr bool kDummy = false;
+        (void)kDummy;
+        const bool two = i0 + 1 < NF;
 #pragma unroll
         for (int s = 0; s < 4 * (i0 + 2); ++s) {
             if (s < 4 * (i0 + 1)) a0 = mfma(Wimg[T::lo(i0, s) * 64 + lane], y[s], a0);
-            a1 = mfma(Wimg[T::lo(i0 + 1, s) * 64 + lane], y[s], a1);
+            if (two) a1 = mfma(Wimg[T::lo(i0 + 1 < NF ? i0 + 1 : i0, s) * 64 + lane], y[s], a1);
         }
         uu += a0.x * a0.x + a0.y * a0.y + a0.z * a0.z + a0.w * a0.w;
-        uu += a1.x * a1.x + a1.y * a1.y + a1.z * a1.z + a1.w * a1.w;
+        if (two) uu += a1.x * a1.x + a1.y * a1.y + a1.z * a1.z + a1.w * a1.w;
     }
     // (with the first tail version -- four coefficients per lane and k-step from LDS -- spreading
     // this tail between the MFMAs spilled at the 256-register cap, 37.5 -> 42..59 ms; with one
     // coefficient per four k-steps there is no read latency left worth hiding)
-    const double ut = tail_rows(Wt, g, cl, y);
+    const double ut = tail_rows<NF>(Wt, g, cl, y);
     uu += ut * ut;
     uu = sum4(uu);
     return -0.5 * ((uu + m.dlog2pi) + m.logdetC);
+}
+
+// the proposal product of k_run_rw_tail: group SG of four k-steps -- its MFMAs over the full row tiles,
+// then its tail FMAs; the next group's tail coefficient is read before the MFMAs that cover the latency
+template <int NF, int SG>
+RMH_DEV void tail_prop_groups(const double *Limg, const double *Lt, TailAcc<NF> &tl, const double (&xi)[4 * (NF + 1)],
+                              double4_t (&acc)[NF], int lane, int g, int cl)
+{
+    using T = Tile<NF + 1>;
+    if constexpr (SG < NF) {
+        tl.load(Lt, g, cl, SG + 1);
+#pragma unroll
+        for (int s = 4 * SG; s < 4 * SG + 4; ++s) {
+#pragma unroll
+            for (int i = SG; i < NF; ++i) acc[i] = mfma(Limg[T::lo(i, s) * 64 + lane], xi[s], acc[i]);
+        }
+        tl.template group<SG>(xi);
+        tail_prop_groups<NF, SG + 1>(Limg, Lt, tl, xi, acc, lane, g, cl);
+    }
 }
 
 // ---- pooled second moments inside the sampling kernel (AdaptCov) --------------------------
@@ -643,23 +674,24 @@ struct MomFused {
     }
 };
 
-template <int NW, bool ADAPT = false, bool PT = false, bool MOM = false>
+template <int NF, int NW, bool ADAPT = false, bool PT = false, bool MOM = false>
 __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
-    constexpr int NT = 7, S = 28, NF = 6, kFull = tri_tiles(NF) * 64; // six full row tiles: 84 tile images
+    constexpr int NT = NF + 1, S = 4 * NT, kFull = tri_tiles(NF) * 64; // NF full row tiles (NF = 6: 84 tile images)
+    constexpr int kTD = tail_doubles(NF), KS = tail_ksteps(NF);   // KS k-steps carry coordinates
     using T = Tile<NT>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *Limg = lds, *Wimg = lds + kFull;
-    double *Lt = Wimg + kFull, *Wt = Lt + kTailDoubles;
-    double *mu = Wt + kTailDoubles;
+    double *Lt = Wimg + kFull, *Wt = Lt + kTD;
+    double *mu = Wt + kTD;
     double *tab = mu + 4 * S;
     double *panels = tab + kIcdfDoubles;   // MOM: two 16-chain panels (MomFused)
-    static_assert(!MOM || (NW == 8 && !ADAPT && !PT), "MomFused: eight wavefronts, plain random walk");
+    static_assert(!MOM || (NF == 6 && NW == 8 && !ADAPT && !PT), "MomFused: d = 97..100, eight wavefronts, plain random walk");
     for (int i = threadIdx.x; i < kFull; i += blockDim.x) {
         Limg[i] = pr.Ltiles[i];
         Wimg[i] = m.Wtiles[i];
     }
-    for (int i = threadIdx.x; i < kTailDoubles; i += blockDim.x) {
+    for (int i = threadIdx.x; i < kTD; i += blockDim.x) {
         Lt[i] = pr.Ltail[i];
         Wt[i] = m.Wtail[i];
     }
@@ -675,13 +707,13 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
     const int64_t c = blk * 16 + cl;
     const int64_t slot = blk * 64 + lane;
 
-    // rows 100..111 of the state are padding (d <= 100): constants here, not three register pairs
+    // the rows of k-steps KS .. S-1 of the state are padding (d <= 16 NF + 4): constants here, not three register pairs
     // carried through the loop for a store of the zeros they were loaded as (round 2 spilled two of
     // them); the stream state and the log posterior through raw buffer instructions (one 32-bit lane
     // offset each instead of five 64-bit addresses held from entry to exit)
     double th[S];
     T::load_state(ch.theta, ch.ld, c, g, th);
-    th[25] = th[26] = th[27] = 0.0;
+    th[KS] = th[KS + 1] = th[KS + 2] = 0.0;
     double lp = buf_load(rsrc(ch.logpost, ch.ld), (uint32_t)c * 8u, 0u);
     Xo rng = xo_load_buf(ch.rng, ch.nslots, slot);
     PtLane pt;
@@ -690,19 +722,19 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         double y0[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) y0[s] = th[s] - mu[4 * s + g];
-        double parts0[2] = {0.0, gauss_loglik(Wimg, Wt, m, lane, g, cl, y0)};
+        double parts0[2] = {0.0, gauss_loglik<NF>(Wimg, Wt, m, lane, g, cl, y0)};
         pt.sL = parts0[1];
         lp = pt.tempered(parts0);
     }
     Keep keep(run);
-    keep.record<NT, 25>(run, ch, 0, c, g, active, th, lp);
+    keep.record<NT, KS>(run, ch, 0, c, g, active, th, lp);
     AdaptScale ad{0.0, 0.0, 1.0};
     if (ADAPT) ad.load(ch, c);
     MomFused mom;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     double *mom_wg = nullptr;
     const bool mom_live = active && c < run.mom_N;
-    if (MOM) {
+    if constexpr (MOM) {
         mom.setup(wave_u, mom_live);
         mom_wg = run.mom_partial + (int64_t)blockIdx.x * (MomFused::NTRI * 256);
     }
@@ -711,7 +743,8 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         asm volatile("" ::: "memory");
         if (PT) pt.select(run, rng, cl);
         double xi[S];
-        T::template normals_fixed<13, 100, MOM ? 2 : 3>(rng, ch.d, g, tab, xi);   // d = 97..100: 13 words
+        // d = 16 NF + 1 .. 16 NF + 4: 2 NF + 1 words per sub-stream, as compile-time constants
+        T::template normals_fixed<2 * NF + 1, 16 * NF + 4, (MOM || NF < 4) ? 2 : 3>(rng, ch.d, g, tab, xi);
         // theta' = theta + scale * L xi: row tiles 0..5 on the matrix core, rows 96..99 on the VALU
         // (ADAPT: the chain's own scale times the unscaled image's product, as in k_run_rw)
         double4_t acc[NF];
@@ -722,24 +755,10 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
             acc[i].z = ADAPT ? 0.0 : th[4 * i + 2];
             acc[i].w = ADAPT ? 0.0 : th[4 * i + 3];
         }
-        TailAcc tl;
+        TailAcc<NF> tl;
         tl.load(Lt, g, cl, 0);
-#pragma unroll
-        for (int sg = 0; sg < NF; ++sg) { // group sg of four k-steps: its MFMAs, then its tail FMAs
-            tl.load(Lt, g, cl, sg + 1);   // next group's entry: the read is covered by the MFMAs
-#pragma unroll
-            for (int s = 4 * sg; s < 4 * sg + 4; ++s) {
-#pragma unroll
-                for (int i = sg; i < NF; ++i) acc[i] = mfma(Limg[T::lo(i, s) * 64 + lane], xi[s], acc[i]);
-            }
-            if (sg == 0) tl.group<0>(xi);
-            if (sg == 1) tl.group<1>(xi);
-            if (sg == 2) tl.group<2>(xi);
-            if (sg == 3) tl.group<3>(xi);
-            if (sg == 4) tl.group<4>(xi);
-            if (sg == 5) tl.group<5>(xi);
-        }
-        tl.group<6>(xi);                  // k-step 24
+        tail_prop_groups<NF, 0>(Limg, Lt, tl, xi, acc, lane, g, cl);
+        tl.template group<NF>(xi);        // k-step 4 NF
         double thp[S];
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
@@ -751,18 +770,18 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         if (ADAPT) {
 #pragma unroll
             for (int s = 0; s < 4 * NF; ++s) thp[s] = th[s] + ad.scale * thp[s];
-            thp[24] = th[24] + ad.scale * tl.finish();
+            thp[4 * NF] = th[4 * NF] + ad.scale * tl.finish();
         } else {
-            thp[24] = th[24] + tl.finish();
+            thp[4 * NF] = th[4 * NF] + tl.finish();
         }
-        thp[25] = thp[26] = thp[27] = 0.0;
+        thp[KS] = thp[KS + 1] = thp[KS + 2] = 0.0;
         // log posterior: |W (theta' - mu)|^2, two row tiles in flight, then the four tail rows
         double y[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) y[s] = thp[s] - mu[4 * s + g];
-        double parts[2] = {0.0, gauss_loglik(Wimg, Wt, m, lane, g, cl, y)};
+        double parts[2] = {0.0, gauss_loglik<NF>(Wimg, Wt, m, lane, g, cl, y)};
         const double lpp = PT ? pt.tempered(parts) : combine_post(0.0, parts[1]);
-        if (MOM) mom.begin(mom_wg, t == 0, lane);   // (no stores in flight here: the record step comes last)
+        if constexpr (MOM) mom.begin(mom_wg, t == 0, lane);   // (no stores in flight here: the record step comes last)
         const double u = T::accept_uniform(rng, g, cl);
         // (MOM: the logarithm's constants as literals at their use -- hoisted to kernel entry they are
         // spilled there, and a scratch reload in the loop waits for every store in flight)
@@ -778,7 +797,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         // BEFORE the record: vmcnt counts loads and stores in one queue, so any wait on a load in
         // the moment phase (the accumulators, a spilled address) would first drain the ~27 history
         // stores of the record step (about 1100 cycles each time, measured with clock64)
-        if (MOM) {
+        if constexpr (MOM) {
             mom.dbg_it = (int)t;
             mom.step(panels, mom_wg, wave_u, lane, ch.d, mom_live, th);
         }
@@ -787,7 +806,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         // reload here waits for every store in flight)
         if (run.h_accept && active && g == 0)
             buf_store_u8(run.h_accept + t * ch.ld, ch.ld, (uint32_t)(g * ch.ld + c), (uint8_t)code);
-        keep.record<NT, 25>(run, ch, t + 1, c, g, active, th, lp);
+        keep.record<NT, KS>(run, ch, t + 1, c, g, active, th, lp);
     }
     if (active) {
         T::store_state(ch.theta, ch.ld, c, g, th);

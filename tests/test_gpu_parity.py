@@ -702,10 +702,11 @@ def test_run_to_disk_streams_the_same_samples(ra, tmp_path):
                 b.current_state()
 
 
-@pytest.mark.parametrize("d", [96, 97, 98, 99, 100, 101])
+@pytest.mark.parametrize("d", [96, 97, 98, 99, 100, 101, 16, 17, 20, 21, 33, 36, 50, 52, 65, 67, 81, 84, 85])
 def test_gauss_random_walk_around_the_tail_kernel_sizes(ra, orc, d):
-    """d = 97..100 run on k_run_rw_tail (rows 96.. on the VALU), 96 and 101 on the generic
-    kernel: all against the oracle, with a changed .scale re-packing both images."""
+    """d = 16 NF + 1 .. 16 NF + 4 (NF = 1..6) run on k_run_rw_tail<NF> (the four rows of the last tile
+    on the VALU), the neighbours on the generic kernel: all against the oracle, with a changed
+    .scale re-packing both images."""
     from riemann_amd.models import MultiGaussianDist
     from riemann_amd.proposals import MetropolisRandomWalk
     g = np.random.default_rng(d)
@@ -728,6 +729,46 @@ def test_gauss_random_walk_around_the_tail_kernel_sizes(ra, orc, d):
     ht, hl, acc = oracle_run(orc, om, orc.RandomWalk(Cp, 0.5), th0, 3, 10)
     np.testing.assert_array_equal(s2._chain_accept, acc)
     np.testing.assert_allclose(s2._chain_thetas, ht, rtol=RTOL, atol=1e-12)
+
+
+@pytest.mark.parametrize("d", [18, 35, 49, 68, 83, 99])
+def test_tail_kernel_variants_vs_oracle_and_generic_kernel(ra, orc, d):
+    """Every k_run_rw_tail<NF> instantiation in its three variants: the per-chain adapted scale and
+    parallel tempering against the oracle, and all three against the generic padded-tile kernel
+    (kernel policy NO_TAIL) -- same stream, same accept decisions, states to the rounding of the
+    four tail rows' summation order."""
+    from riemann_amd._lib import kernel_policy
+    from riemann_amd.models import MultiGaussianDist
+    from riemann_amd.proposals import AdaptScaleRandomWalk, MetropolisRandomWalk
+    from riemann_amd.samplers import PTSampler
+    g = np.random.default_rng(1000 + d)
+    A = g.standard_normal((d, d))
+    Ct = A @ A.T / d + 0.3 * np.eye(d)
+    mu = g.standard_normal(d)
+    Cp = (2.38 ** 2 / d) * Ct
+    th0 = mu + g.standard_normal((150, d))
+    m, om = MultiGaussianDist(mu, Ct), orc.Gaussian(mu, Ct)
+    out = {}
+    for pol in ((), ("NO_TAIL",)):
+        with kernel_policy(*pol):
+            a = ra.Sampler(m, MetropolisRandomWalk(Cp), th0, seed=5, chain0=32)
+            a.run(12, 2, 2)
+            b = ra.Sampler(m, AdaptScaleRandomWalk(Cp), th0, seed=6)
+            b.run(25)
+            pt = PTSampler(m, MetropolisRandomWalk(Cp), th0[:40], betas=0.6 ** np.arange(4), Pswap=0.3, seed=7)
+            pt.run(20)
+            out[pol] = (a._chain_accept.copy(), a._chain_thetas.copy(), b._chain_accept.copy(), b._chain_thetas.copy(),
+                        np.asarray(b.proposal.scale).copy(), pt._host_codes.copy(), pt._host_thetas.copy())
+    t, gnr = out[()], out[("NO_TAIL",)]
+    for k in (0, 2, 5):
+        np.testing.assert_array_equal(t[k], gnr[k])
+    for k in (1, 3, 4, 6):
+        np.testing.assert_allclose(t[k], gnr[k], rtol=1e-9, atol=1e-12)
+    # adapted scale against the oracle
+    th, st, ad = th0.copy(), orc.rng_seed(6, 150), orc.new_adapt_state(150)
+    ht, hl, acc = orc.run(om, orc.set_adapt(orc.RandomWalk(Cp), 0.25), th, om.log_posterior(th), st, 25, adapt=ad)
+    np.testing.assert_array_equal(t[2], acc)
+    np.testing.assert_allclose(t[3], ht, rtol=RTOL, atol=1e-12)
 
 
 @pytest.mark.gpu

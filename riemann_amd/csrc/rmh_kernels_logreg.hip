@@ -60,10 +60,14 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
         // second wave cannot overlap VALU with MFMA on this chip, but it fills the
         // s_waitcnt / barrier gaps of the stage loop: 0.52 -> 0.61 of the FP64 roof,
         // although the 256-register cap costs ~300 spilled registers outside the loop.
-        constexpr int NW = (kNT >= 5) ? 8 : 4;
-        if constexpr (kNT == 7) { // d = 97..100: columns 96..99 of the gradient on the VALU (rmh_models.hpp)
-            if (m.ks == 25 && r.pt_K == 0 && !p.chM && !policy(RMH_POLICY_NO_TAIL)) {
-                using MT = LogRegModel<7, true>;
+        // (round 3: the link-function table and the inverse-CDF table alone are 78 KB of LDS, so there is ONE
+        // workgroup per CU whatever the dimension: with four waves the small dimensions ran one wave per
+        // SIMD -- d = 64 took 4.25 ms per iteration where d = 68, the first eight-wave size, took 3.53.
+        // Eight waves for every dimension; sixteen at d <= 16 spill 100 registers at the 128 cap.)
+        constexpr int NW = 8;
+        if constexpr (kNT >= 2) { // d = 16 NF + 1 .. 16 NF + 4: the last column tile of the gradient on the VALU (rmh_models.hpp)
+            if (m.ks == 4 * (kNT - 1) + 1 && r.pt_K == 0 && !p.chM && !policy(RMH_POLICY_NO_TAIL)) {
+                using MT = LogRegModel<(kNT >= 2 ? kNT : 2), true>;   // (kNT = 1 never gets here; the launcher is not a template)
                 if (adapt) return launch(k_run_hmc<MT, NW, true, false>, c.nblocks, NW, lds, st, m, p, c, r);
                 return launch(k_run_hmc<MT, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);
             }

@@ -22,7 +22,7 @@ struct GaussModel {
     using Args = GaussArgs;
     using T = Tile<NT>;
     static constexpr int S = T::S;
-    static constexpr bool kDim100 = false;          // d known to be 97..100 at compile time
+    static constexpr int kTailNF = 0;               // > 0: d = 16 NF + 1 .. 16 NF + 4 known at compile time
     static constexpr int kImg = tri_tiles(NT) * 64; // doubles per triangular image
 
     static constexpr __host__ __device__ size_t lds_doubles(bool grad) { return (size_t)kImg * (grad ? 2 : 1) + 4 * S; }
@@ -112,7 +112,7 @@ struct MixModel {
     using Args = MixArgs;
     using T = Tile<NT>;
     static constexpr int S = T::S;
-    static constexpr bool kDim100 = false;
+    static constexpr int kTailNF = 0;
     static constexpr int kImg = tri_tiles(NT) * 64;
 
     static constexpr __host__ __device__ size_t lds_doubles(bool) { return 0; }
@@ -195,15 +195,16 @@ struct MixModel {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
-// GT ("gradient tail", d = 97..100 only): the seventh 16-column tile of the gradient product holds
-// 4 real columns; v_mfma_f64 and the VALU share the FP64 units on this chip, so those 4 columns
+// GT ("gradient tail", d = 16 NF + 1 .. 16 NF + 4 with NF = NT - 1; round 2: d = 97..100 only): the last
+// 16-column tile of the gradient product holds at most 4 real columns; v_mfma_f64 and the VALU share
+// the FP64 units on this chip, so those 4 columns
 // are cheaper as 16 DPP fmas per row tile than as 4 MFMAs (as the four tail rows of
-// k_run_rw_tail, rmh_run.hpp): lane (g, cl = 4r + c) reads X[row 4r+g][column 96+c] with ONE
+// k_run_rw_tail, rmh_run.hpp): lane (g, cl = 4r + c) reads X[row 4r+g][column 16 NF + c] with ONE
 // ds_read_b64, the fmas take it by row broadcast, and every lane accumulates its own data rows'
 // share of the four columns; the chain's four lanes meet once per evaluation (sum4_scatter).
 template <int NT, bool GT = false>
 struct LogRegModel {
-    static_assert(!GT || NT == 7, "the gradient tail is the d = 97..100 case");
+    static_assert(!GT || NT >= 2, "the gradient tail needs at least one full column tile");
     using Args = LogRegArgs;
     using T = Tile<NT>;
     static constexpr int S = T::S;
@@ -211,9 +212,9 @@ struct LogRegModel {
     static constexpr int XT = 256 * NT;            // doubles of one row tile's X tiles
     static constexpr int CHD = kChunkDoubles(NT);  // doubles per stage
     static constexpr int NP = CHD / 128;           // 1-KiB DMA pieces per stage
-    static constexpr bool kDim100 = GT;
+    static constexpr int kTailNF = GT ? NT - 1 : 0; // > 0: d = 16 NF + 1 .. 16 NF + 4 is a compile-time fact
     static constexpr int NG = GT ? NT - 1 : NT;    // gradient row tiles on the matrix core
-    static constexpr int KS = GT ? 25 : 0;         // k-steps of eta when known at compile time
+    static constexpr int KS = GT ? 4 * (NT - 1) + 1 : 0;   // k-steps of eta when known at compile time
 
     static constexpr __host__ __device__ size_t lds_doubles(bool) { return (size_t)2 * CHD + kLogiDoubles; }
     // LDS: [stage 0][stage 1][link-function table]
@@ -312,7 +313,7 @@ struct LogRegModel {
             }
             double xv = 0.0, a0[NG];
             if (GRAD) {
-                if (GT) xv = img[24 * 64 + toff];
+                if (GT) xv = img[(4 * (NT - 1)) * 64 + toff];   // the tile of k-step 4 NF: columns 16 NF ..
 #pragma unroll
                 for (int i = 0; i < NG; ++i) a0[i] = img[i * 256 + goff[0]];
             }
@@ -361,8 +362,8 @@ struct LogRegModel {
             eoff[k] = g * 16 + (cl ^ ((k << 2) | g));
             goff[k] = (cl >> 2) * 64 + (cl & 3) * 16 + ((4 * k + g) ^ cl);
         }
-        // gradient tail: lane (g, cl = 4r + c) holds X[row 4r + g][column 96 + c] = tile 24,
-        // slot c*16 + (row ^ F) with F = c (image layout above)
+        // gradient tail: lane (g, cl = 4r + c) holds X[row 4r + g][column 16 NF + c] = tile 4 NF,
+        // slot c*16 + (row ^ F) with F = c (image layout above: s & 3 = 0 for s = 4 NF)
         const int toff = (cl & 3) * 16 + ((4 * (cl >> 2) + g) ^ (cl & 3));
         double4_t G[NG];
 #pragma unroll
@@ -400,9 +401,9 @@ struct LogRegModel {
                 grad[4 * i + 2] = G[i].z;
                 grad[4 * i + 3] = G[i].w;
             }
-            if (GT) { // rows 96..99: lane group g keeps row 96 + g (tile 6, register 0)
-                grad[24] = sum4_scatter(gt.t0, gt.t1, gt.t2, gt.t3);
-                grad[25] = grad[26] = grad[27] = 0.0;
+            if (GT) { // rows 16 NF ..: lane group g keeps row 16 NF + g (tile NF, register 0)
+                grad[4 * (NT - 1)] = sum4_scatter(gt.t0, gt.t1, gt.t2, gt.t3);
+                grad[4 * (NT - 1) + 1] = grad[4 * (NT - 1) + 2] = grad[4 * (NT - 1) + 3] = 0.0;
             }
 #pragma unroll
             for (int s = 0; s < S; ++s) grad[s] = grad[s] * 0.0625 - th[s] * m.inv_tau2;   // (16 X)^T res / 16: exact

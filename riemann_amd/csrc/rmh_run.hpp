@@ -907,9 +907,9 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
             }
         }
         if (t < run.T) {
-            // d = 97..100 (the model's compile-time case): 13 words per sub-stream, no wave-uniform
-            // word and k-step predicates (rmh_mfma.hpp)
-            if constexpr (M::kDim100) T::template normals_fixed<13, 100>(rng, ch.d, g, tab, p);
+            // d = 16 NF + 1 .. 16 NF + 4 (the model's compile-time case): 2 NF + 1 words per sub-stream,
+            // no wave-uniform word and k-step predicates (rmh_mfma.hpp)
+            if constexpr (M::kTailNF > 0) T::template normals_fixed<2 * M::kTailNF + 1, 16 * M::kTailNF + 4>(rng, ch.d, g, tab, p);
             else T::normals(rng, ch.M, ch.d, g, tab, p);
         }
         T::load_state(ch.theta, ch.ld, c, g, q);

@@ -308,6 +308,46 @@ def test_logreg_mala_256_chains(ra, orc):
     np.testing.assert_allclose(s._chain_logpost, hl, rtol=RTOL)
 
 
+@pytest.mark.parametrize("d", [18, 36, 49, 68, 84])
+def test_logreg_gradient_tail_for_every_tile_count_vs_oracle(ra, orc, d):
+    """d = 16 NF + 1 .. 16 NF + 4: the last column tile of the logistic gradient on the VALU
+    (LogRegModel<NT, true>, round 2: d = 97..100 only) -- MALA, HMC and the adapted-scale HMC against
+    the oracle, and against the padded-tile kernel (kernel policy NO_TAIL)."""
+    from riemann_amd._lib import kernel_policy
+    from riemann_amd.models import LogisticRegression
+    from riemann_amd.proposals import MALA, AdaptScaleHMC, VanillaHMC
+    from riemann_amd.workloads import logreg_data
+    X, y = logreg_data(700, d, seed=d)
+    th0 = 0.05 * np.random.default_rng(d).standard_normal((200, d))
+    m = LogisticRegression(X, y, 50.0)
+    om = orc.LogReg(X, y, 50.0)
+    out = {}
+    for pol in ((), ("NO_TAIL",)):
+        with kernel_policy(*pol):
+            a = ra.Sampler(m, MALA(0.1, m), th0, seed=3)
+            a.run(8)
+            b = ra.Sampler(m, VanillaHMC(0.06, 4, m), th0, seed=4, chain0=16)
+            b.run(5)
+            c = ra.Sampler(m, AdaptScaleHMC(0.08, 2, m), th0, seed=5)
+            c.run(10)
+            out[pol] = [(x._chain_accept.copy(), x._chain_thetas.copy(), x._chain_logpost.copy()) for x in (a, b, c)]
+    for t, gnr in zip(out[()], out[("NO_TAIL",)]):
+        np.testing.assert_array_equal(t[0], gnr[0])
+        np.testing.assert_allclose(t[1], gnr[1], rtol=1e-9, atol=1e-12)
+    ht, hl, acc = oracle_run(orc, om, orc.HMC(0.1, 1, d), th0, 3, 8)
+    np.testing.assert_array_equal(out[()][0][0], acc)
+    np.testing.assert_allclose(out[()][0][1], ht, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(out[()][0][2], hl, rtol=RTOL)
+    th, st = th0.copy(), orc.rng_seed(4, 200, chain0=16)
+    ht, hl, acc = orc.run(om, orc.HMC(0.06, 4, d), th, om.log_posterior(th), st, 5)
+    np.testing.assert_array_equal(out[()][1][0], acc)
+    np.testing.assert_allclose(out[()][1][1], ht, rtol=RTOL, atol=1e-12)
+    th, st, ad = th0.copy(), orc.rng_seed(5, 200), orc.new_adapt_state(200)
+    ht, hl, acc = orc.run(om, orc.set_adapt(orc.HMC(0.08, 2, d), 0.75), th, om.log_posterior(th), st, 10, adapt=ad)
+    np.testing.assert_array_equal(out[()][2][0], acc)
+    np.testing.assert_allclose(out[()][2][1], ht, rtol=RTOL, atol=1e-12)
+
+
 def test_full_size_sharding_and_resume_invariance(ra):
     """65 536 chains (cfg2): (i) the chains of a shard started with chain0 = a
     equal chains [a, b) of the whole job -- the multi-GPU partition is exact;

@@ -31,6 +31,21 @@ RMH_DEV double reg(double x)
 // comparison becomes a branch (22.5 ms; this form: 21.6 ms).  One asm per comparison, so that the
 // two wait states a VALU-written lane mask needs before a VALU read are there by construction
 // (the compiler pads such pairs itself but does not look inside asm).
+// "This value has arrived": an empty asm that reads x.  gfx9 counts loads and stores in ONE in-order
+// vmcnt queue, and the compiler puts the wait for a value loaded before a loop at its first use INSIDE
+// the loop -- where, from the second iteration on, it waits for nothing but the previous iteration's
+// history stores (a drain of ~1000 cycles per iteration in the one-wave-per-SIMD kernels below).
+// Touching every such value before the loop moves the wait there.
+RMH_DEV void arrived(double x) { asm volatile("" ::"v"(x)); }
+RMH_DEV void arrived(uint64_t x) { asm volatile("" ::"v"(x)); }
+RMH_DEV void arrived(const Xo &x)
+{
+    arrived(x.s0);
+    arrived(x.s1);
+    arrived(x.s2);
+    arrived(x.s3);
+}
+
 RMH_DEV void sel_lt(uint32_t &lo, uint32_t &hi, double a, double x, double y)
 {
     const uint64_t u = (uint64_t)__double_as_longlong(y);
@@ -598,6 +613,13 @@ __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainAr
         st[b] = xo_load(ch.rng, ch.nslots, slot);
     }
 
+    // the proposal's diagonal factor in registers (round 2 read it inside the loop: behind the memory
+    // fence below the compiler re-issued six vector loads per iteration, and their vmcnt wait drained
+    // the previous iteration's history stores)
+    double ldg[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) ldg[j] = pr.Ldiag[j];
+
     int64_t knext = run.nburn, kentry = 0;
     auto rec = [&](int64_t e) {
         if (e != knext) return;
@@ -611,6 +633,15 @@ __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainAr
         buf_store(rsrc(run.h_logpost + k * ch.ld, ch.ld), (uint32_t)c * 8u, 0u, lp);
     };
     rec(0);
+    // everything loaded so far has arrived before the loop starts (see `arrived`)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        arrived(th[j]);
+        arrived(ldg[j]);
+    }
+    arrived(lp);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) arrived(st[b]);
 
     const double kpc = (double)KP * (m.c_v - m.lgam_alpha);
     for (int64_t t = 0; t < run.T; ++t) {
@@ -669,10 +700,10 @@ __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainAr
             if (dr[D + 1] < pr.blk_p[0]) pk = 0;
             const double mb[3] = {pk == 0 ? 1.0 : 0.0, pk == 1 ? 1.0 : 0.0, pk == 2 ? 1.0 : 0.0};
 #pragma unroll
-            for (int j = 0; j < D; ++j) tp[j] = fma_(pr.Ldiag[j] * mb[j < KC ? 0 : (j < D - 1 ? 1 : 2)], dr[j], th[j]);
+            for (int j = 0; j < D; ++j) tp[j] = fma_(ldg[j] * mb[j < KC ? 0 : (j < D - 1 ? 1 : 2)], dr[j], th[j]);
         } else {
 #pragma unroll
-            for (int j = 0; j < D; ++j) tp[j] = fma_(pr.Ldiag[j], dr[j], th[j]);
+            for (int j = 0; j < D; ++j) tp[j] = fma_(ldg[j], dr[j], th[j]);
         }
         // ---- prior (changepoint.py:128-160, alpha = 1: see k_cp_rw_ss)
         double prod = 1.0, dmin = __builtin_huge_val(), vsum = 0.0, vmin = __builtin_huge_val();
@@ -1411,6 +1442,15 @@ __global__ void __launch_bounds__(256) k_cprj_run64(CpRjArgs m, ChainArgs ch, Ru
         run.h_logpost[kk * ch.ld + c] = lp;
     };
     rec(0);
+    // everything loaded so far has arrived before the loop starts (see `arrived`)
+#pragma unroll
+    for (int j = 0; j < KD; ++j) arrived(th.cpx[j]);
+#pragma unroll
+    for (int j = 0; j < KP; ++j) arrived(th.cpv[j]);
+    arrived(th.sig);
+    arrived(lp);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) arrived(st[b]);
 
     const int MW = (Dn + 7) / 8;
     for (int64_t t = 0; t < run.T; ++t) {

@@ -486,9 +486,9 @@ struct MomFused {
     //   for the writer at the next barrier.  So the write is LDS instructions only: addresses are
     //   formed once per iteration before the first barrier (`wa`: row g, column cl of panel 0;
     //   `ca`: row 0, column cl), everything else is an immediate offset.
-    // * Single ds_write_b64, as inline asm: left to itself the compiler pairs the stores into
-    //   ds_write2_b64, which wants 16-byte aligned elements -- with chains 8 bytes apart half the
-    //   lanes are not, and every such instruction is replayed at ~90 cycles.
+    // * Single ds_write_b64 with immediate offsets, as inline asm: left to itself the compiler pairs the
+    //   stores into ds_write2_b64, whose 8-bit offsets do not reach across the panel, and materialises
+    //   ten row addresses (v_add_u32) plus a spilled base (scratch_load + vmcnt(0)) in front of them.
     // * Common path (every chain of the wave live): 28 stores of the state registers (rows > d of
     //   the state are zero), then the constant 1 into row d by all four lanes of a chain (same
     //   address, same value).  Only a wave with padding chains pays selects.

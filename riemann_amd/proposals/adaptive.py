@@ -97,7 +97,7 @@ class AdaptScaleProposal(DeviceProposal):
             if getattr(self, "_host_scale", None) is None:
                 self._host_scale = np.atleast_1d(np.asarray(self.scale, dtype=np.float64))
             return self._propose_host(theta, rng)
-        if not isinstance(self, MetropolisRandomWalk) or isinstance(self, pCN) or hasattr(self, "C0"):
+        if not isinstance(self, MetropolisRandomWalk) or isinstance(self, pCN):
             raise NotImplementedError("stand-alone propose() of this adaptive proposal is not built: "
                                       "its state lives with the Sampler's chains")
         th = _lib.as_f64(theta)
@@ -157,5 +157,8 @@ class AdaptCovProposal(DeviceProposal):
         self.C = st[1 + d + d * d:1 + d + 2 * d * d].reshape(d, d).copy()
         self.L = st[1 + d + 2 * d * d:1 + d + 3 * d * d].reshape(d, d).copy()
 
-    def propose(self, theta):
-        raise NotImplementedError("stand-alone propose() of an adaptive proposal is not built")
+    def propose(self, theta, rng=None):
+        """Stand-alone form with the CURRENT adapted factor: theta + L xi (randomwalk.py:26 with the L of
+        adaptive.py:101-102), or the trajectory with the current mass matrix for the HMC variant
+        (hamiltonian.py:117-119) -- what the reference's propose() does between two adapt() calls."""
+        return DeviceProposal.propose(self, theta, rng=rng)

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Randomised differential test: random (model, proposal, d, N, T, Nburn, Nthin) configurations on
-the device against the CPU oracle.  Test infrastructure (uses oracle/).   python tools/fuzz_vs_oracle.py [n] [seed]"""
+the device against the CPU oracle.  Test infrastructure (uses oracle/).   python tools/fuzz_vs_oracle.py [n] [seed]
+
+Every configuration runs under a random kernel policy (riemann_amd._lib.kernel_policy: half of them the
+library's own choice, the others a random subset of the A/B switches), so that the specialised kernels --
+one-lane-per-chain changepoint kernels at small chain counts, the VALU tail rows against the padded tiles,
+the in-kernel moments of the covariance adaptation against the scratch history -- all meet the oracle."""
 import os
 import sys
 import traceback
@@ -71,8 +76,8 @@ def one(g, it):
     if kind == "cprj":
         return one_cprj(g)
     dmax = {"gauss": 112, "logreg": 112, "mix": 100, "cp": 18, "bigd": 1024}[kind]
-    d = int(g.choice([1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 79, 80, 81, 95, 96, 97, 100, 111, 112,
-                      int(g.integers(1, 113)), int(g.integers(33, 97))]))
+    d = int(g.choice([1, 2, 3, 4, 5, 15, 16, 17, 20, 31, 32, 33, 36, 47, 48, 49, 52, 63, 64, 65, 68, 79, 80, 81, 84, 95, 96, 97, 100,
+                      111, 112, int(g.integers(1, 113)), int(g.integers(33, 97))]))
     d = min(d, dmax)
     if kind == "bigd":
         d = int(g.choice([113, 127, 128, 129, 256, 257, 300, 512, 513, int(g.integers(113, 700))]))
@@ -238,17 +243,35 @@ def one(g, it):
     return desc
 
 
+def random_policy(gp):
+    """() half of the time, else a random subset of the kernel switches"""
+    if gp.uniform() < 0.5:
+        return ()
+    names = ["NO_TAIL", "CP_NO_SS", "CP_NO_BUCKETS", "CPRJ_NO_SS", "ACOV_HOST", "ACOV_UNFUSED"]
+    pol = [n for n in names if gp.uniform() < 0.3]
+    r = gp.uniform()
+    if r < 0.45:
+        pol.append("CP_SS64")
+    elif r < 0.6:
+        pol.append("CP_SS16")
+    return tuple(pol)
+
+
 def main():
+    from riemann_amd._lib import kernel_policy
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    g = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    g, gp = np.random.default_rng(seed), np.random.default_rng(seed + 977)
     bad = 0
     for it in range(n):
+        pol = random_policy(gp)
         try:
-            d = one(g, it)
-            print("ok  ", d, flush=True)
+            with kernel_policy(*pol):
+                d = one(g, it)
+            print("ok  ", d, ("[" + ",".join(pol) + "]") if pol else "", flush=True)
         except Exception as e:           # keep going: collect every failing configuration
             bad += 1
-            print("FAIL", repr(e)[:300], flush=True)
+            print("FAIL", "[" + ",".join(pol) + "]", repr(e)[:300], flush=True)
             traceback.print_exc(limit=2)
     print("%d configurations, %d failed" % (n, bad))
     sys.exit(1 if bad else 0)

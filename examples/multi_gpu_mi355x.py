@@ -45,6 +45,13 @@ if group.rank == 0:
     print("%d ranks, %d chains pooled (%.1f MB per rank in %.2f ms); |mean|max %.3f, mean variance %.3f (target 1.0)"
           % (info["rccl_ranks"], info["pooled_chains"], info["allgather_bytes_per_rank"] / 1e6, info["allgather_ms"],
              np.abs(mean).max(), np.diag(cov).mean()))
+# diagnostics of a recorded stretch over the chains of ALL ranks: every rank reduces its device history, the ranks
+# exchange a few small all-reduces, and every rank gets the numbers one process with all chains would report
+s.run(8000, 0, 80)
+st = D.pool_history(s, nlags=64, samples_every=25)
+if group.rank == 0:
+    print("pooled over %d chains: split R-hat max %.4f, tau_int max %.1f kept states, ESS min %.3g; %d thinned samples "
+          "of every chain gathered" % (st["chains"], st["rhat"].max(), st["tau"].max(), st["ess"].min(), st["samples"].shape[0]))
 _lib.call("rmh_comm_barrier")
 _lib.call("rmh_comm_destroy")
 group.close()

@@ -460,7 +460,9 @@ struct MomFused {
     int po[TPW];            // offsets of its accumulator tiles in the workgroup's partial, -1: unused slot
     double4_t acc[TPW];
     bool all_live = true;   // every chain of the wave counts (wave-uniform)
-    int dbg_it = 0;
+#if RMH_MOM_ABL == 9
+    int dbg_it = 0;   // iteration number, for the clock64 print of the ablation build
+#endif
 
     RMH_DEV void setup(int wave, bool live)
     {
@@ -525,7 +527,7 @@ struct MomFused {
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
             acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
-            if (!first && po[tt] >= 0 && RMH_MOM_ABL != 4) {
+            if (!first && po[tt] >= 0) {
                 const double *src = partial_wg + po[tt] + lane;
                 acc[tt].x = src[0];
                 acc[tt].y = src[64];
@@ -663,7 +665,7 @@ struct MomFused {
         // before the barrier of round 7; its second write comes after a barrier of its own)
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
-            if (po[tt] >= 0 && RMH_MOM_ABL != 4) {
+            if (po[tt] >= 0) {
                 double *dst = partial_wg + po[tt] + lane;
                 dst[0] = acc[tt].x;
                 dst[64] = acc[tt].y;
@@ -798,7 +800,9 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         // the moment phase (the accumulators, a spilled address) would first drain the ~27 history
         // stores of the record step (about 1100 cycles each time, measured with clock64)
         if constexpr (MOM) {
+#if RMH_MOM_ABL == 9
             mom.dbg_it = (int)t;
+#endif
             mom.step(panels, mom_wg, wave_u, lane, ch.d, mom_live, th);
         }
         // (the accept byte through a buffer store at the state rows' lane offset / 8: a flat store keeps

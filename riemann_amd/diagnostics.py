@@ -108,7 +108,7 @@ ACF_SCALE = 1099511627776.0   # 2^40, include/riemann_hip.h RMH_ACF_SCALE
 def exact_partial(x):
     """The exact sum of the 1-D array ``x`` as three doubles (hi, lo, lo2)."""
     import math
-    v = [float(t) for t in np.asarray(x, dtype=np.float64).ravel()]
+    v = np.asarray(x, dtype=np.float64).ravel().tolist()
     hi = math.fsum(v)
     lo = math.fsum(v + [-hi])
     lo2 = math.fsum(v + [-hi, -lo])

@@ -120,6 +120,7 @@ struct RunArgs {
     // >= mom_N (padding) do not count.  Null: off.
     double *mom_partial;
     int64_t mom_N;
+    int mom_passes;     // chain sets per workgroup (the grid is sized to one workgroup per CU)
 };
 
 struct RwArgs {
@@ -170,9 +171,9 @@ hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const Ch
                            const RunArgs &r, bool adapt, hipStream_t st);
 hipError_t launch_gauss_rw_tail(const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                                 const RunArgs &r, bool adapt, hipStream_t st);
-// workgroups of launch_gauss_rw_tail for `nblocks` 16-chain blocks (= partial sums written
-// when r.mom_partial is set)
-int64_t gauss_rw_tail_workgroups(int64_t nblocks);
+// grid of launch_gauss_rw_tail with r.mom_partial set, for `nblocks` 16-chain blocks: workgroups (= partial
+// sums written) and the chain sets each of them takes (RunArgs::mom_passes)
+int64_t gauss_rw_tail_mom_grid(int64_t nblocks, int *passes);
 hipError_t launch_gauss_pt(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,
                            const RunArgs &r, hipStream_t st);
 hipError_t launch_mix_eval(int NT, const MixArgs &m, const ChainArgs &c, int want_grad, double *lp_out,

@@ -52,7 +52,10 @@ static hipError_t gauss_rw_tail_launch(const GaussArgs &m, const RwArgs &p, cons
     if (r.mom_partial) { // AdaptCov: the pooled moments of the states 1..T accumulated in the kernel
         if constexpr (NF == 6) {
             if (r.pt_K > 0 || adapt) return hipErrorInvalidValue;
-            return launch(k_run_rw_tail<6, 8, false, false, true>, c.nblocks, 8, lds + sizeof(double) * 2 * kMomPanel,
+            int passes = 1;
+            const int64_t grid = gauss_rw_tail_mom_grid(c.nblocks, &passes);
+            if (passes != r.mom_passes) return hipErrorInvalidValue;
+            return launch(k_run_rw_tail<6, 8, false, false, true>, grid * 8, 8, lds + sizeof(double) * 2 * kMomPanel,
                           st, m, p, c, r);
         }
         return hipErrorInvalidValue;
@@ -76,7 +79,19 @@ hipError_t launch_gauss_rw_tail(const GaussArgs &m, const RwArgs &p, const Chain
     }
 }
 
-int64_t gauss_rw_tail_workgroups(int64_t nblocks) { return (nblocks + 7) / 8; }
+int64_t gauss_rw_tail_mom_grid(int64_t nblocks, int *passes)
+{
+    const int64_t nwg = (nblocks + 7) / 8;
+    int cus = 256;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    int64_t np = (nwg + cus - 1) / cus;           // one workgroup per CU, as many chain sets as that takes
+    np = np < 1 ? 1 : np > 16 ? 16 : np;
+    *passes = (int)np;
+    return (nwg + np - 1) / np;
+}
 
 // parallel tempering over a Gaussian target: one wave per SIMD (register budget)
 hipError_t launch_gauss_pt(int NT, const GaussArgs &m, const RwArgs &p, const ChainArgs &c,

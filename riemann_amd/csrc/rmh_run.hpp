@@ -703,7 +703,13 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cl = lane & 15, g = lane >> 4;
-    int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    // MOM: a workgroup takes run.mom_passes sets of 8 x 16 chains one after the other (the host sizes the
+    // grid to one workgroup per CU): the 114 KB of tile images and tables are staged once per launch instead
+    // of once per set -- an AdaptCov stretch is one or two iterations long on the reference's schedule, so
+    // the staging was a third of a launch -- and there are half as many partial sums to add up afterwards
+    const int npass = MOM ? run.mom_passes : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+    int64_t blk = ((int64_t)pass * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave;
     const bool active = blk < ch.nblocks;
     if (!active) blk = ch.nblocks - 1;
     const int64_t c = blk * 16 + cl;
@@ -783,7 +789,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         for (int s = 0; s < S; ++s) y[s] = thp[s] - mu[4 * s + g];
         double parts[2] = {0.0, gauss_loglik<NF>(Wimg, Wt, m, lane, g, cl, y)};
         const double lpp = PT ? pt.tempered(parts) : combine_post(0.0, parts[1]);
-        if constexpr (MOM) mom.begin(mom_wg, t == 0, lane);   // (no stores in flight here: the record step comes last)
+        if constexpr (MOM) mom.begin(mom_wg, pass == 0 && t == 0, lane);   // (no stores in flight here: the record step comes last)
         const double u = T::accept_uniform(rng, g, cl);
         // (MOM: the logarithm's constants as literals at their use -- hoisted to kernel entry they are
         // spilled there, and a scratch reload in the loop waits for every store in flight)
@@ -818,6 +824,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         if (ADAPT && g == 0) ad.store(ch, c);
         xo_store_buf(ch.rng, ch.nslots, slot, rng);
     }
+    }   // pass
 }
 
 // ------------------------------------------------------------ HMC / MALA ----

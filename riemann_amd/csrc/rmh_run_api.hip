@@ -234,7 +234,8 @@ static int run_adaptcov(rmh_model *m, rmh_proposal *p, rmh_state *s, const Chain
     const int64_t rows = 4 * s->ks, ld = s->ld;
     const bool fused = p->kind == kRW && m->kind == kGauss && m->ga.Wtail && p->d_Ltail && !c.adapt &&
                        p->acov_NT == 7 && !policy(RMH_POLICY_NO_TAIL) && !policy(RMH_POLICY_ACOV_UNFUSED);
-    const int64_t nwg = fused ? gauss_rw_tail_workgroups(c.nblocks) : kAcovWGs;
+    int mom_passes = 1;
+    const int64_t nwg = fused ? gauss_rw_tail_mom_grid(c.nblocks, &mom_passes) : kAcovWGs;
     const size_t need = (size_t)nwg * acov_ntri(p) * 256;
     if (p->acov_partial_cap < need) {
         (void)hipFree(p->d_acov_partial);
@@ -280,6 +281,7 @@ static int run_adaptcov(rmh_model *m, rmh_proposal *p, rmh_state *s, const Chain
             }
             r.mom_partial = p->d_acov_partial;
             r.mom_N = s->N;
+            r.mom_passes = mom_passes;
             RwArgs ra{p->d_Ltiles, nullptr, 0.0};
             ra.Ltail = p->d_Ltail;
             RMH_HIP(launch_gauss_rw_tail(m->ga, ra, c, r, false, g_stream));

@@ -85,6 +85,81 @@ RMH_DEV void buf_store_u8(uint8_t *base, int64_t bytes, uint32_t voff, uint8_t x
     __builtin_amdgcn_raw_buffer_store_b8(x, r, voff, 0, 0);
 }
 
+// ---- triangular products with the tile image streamed from global memory (L2) ----------------
+// pCN's (rho_c L)^-1 and the mass-matrix images of HMC do not fit LDS next to the model's own
+// images, so those products read their A operands from L2, ~800 cycles away, on a SIMD the wave has
+// to itself.  TriSeq is the order in which a product consumes the (tile row i, k-step s) slices
+// (s-major: consecutive MFMAs go to different accumulators) with each slice's index in the image;
+// tri_stream keeps kStreamChunk slices in flight ahead of the MFMAs through raw buffer loads
+// (descriptor in SGPRs, one lane-offset VGPR, the slice offset an immediate/scalar) and feeds
+// every loaded slice to NV right-hand sides.  (Before round 3 these products issued their loads
+// two k-steps at a time behind a scheduling fence: latency-bound, mass-matrix HMC ran at 10x the
+// identity-mass time.)
+constexpr int kStreamChunk = 16;
+
+template <int NT, bool UPPER>
+struct TriSeq {
+    static constexpr int S = 4 * NT, N = 2 * NT * (NT + 1);
+    int i[N], s[N], idx[N];
+    constexpr TriSeq() : i{}, s{}, idx{}
+    {
+        int n = 0;
+        for (int ss = 0; ss < S; ++ss)
+            for (int ii = (UPPER ? 0 : ss / 4); ii < (UPPER ? ss / 4 + 1 : NT); ++ii) {
+                i[n] = ii;
+                s[n] = ss;
+                idx[n] = UPPER ? ii * S - 2 * ii * (ii - 1) + (ss - 4 * ii) : 2 * ii * (ii + 1) + ss;
+                ++n;
+            }
+    }
+};
+
+template <int NT, bool UPPER, int C>
+RMH_DEV void tri_stream_fetch(__amdgpu_buffer_rsrc_t img, uint32_t voff, double (&buf)[kStreamChunk])
+{
+    constexpr TriSeq<NT, UPPER> seq{};
+#pragma unroll
+    for (int k = 0; k < kStreamChunk; ++k) {
+        constexpr int N = TriSeq<NT, UPPER>::N;
+        const int n = C * kStreamChunk + k < N ? C * kStreamChunk + k : N - 1;
+        buf[k] = buf_load(img, voff, (uint32_t)seq.idx[n] * 512u);
+    }
+}
+
+template <int NT, bool UPPER, int NV, int C>
+RMH_DEV void tri_stream_chunk(__amdgpu_buffer_rsrc_t img, uint32_t voff, const double (&B)[NV][4 * NT],
+                              double4_t (&acc)[NV][NT], int ks, double (&cur)[kStreamChunk])
+{
+    constexpr TriSeq<NT, UPPER> seq{};
+    constexpr int N = TriSeq<NT, UPPER>::N, S = 4 * NT;
+    constexpr int NCH = (N + kStreamChunk - 1) / kStreamChunk;
+    double nxt[kStreamChunk];
+    if constexpr (C + 1 < NCH) tri_stream_fetch<NT, UPPER, C + 1>(img, voff, nxt);
+#pragma unroll
+    for (int k = 0; k < kStreamChunk; ++k) {
+        const int n = C * kStreamChunk + k;
+        if (n < N) {
+            const int i = seq.i[n], s = seq.s[n];
+            if (s < S - 4 || s < ks) { // k-steps >= ks = ceil(d/4) carry zeros (Tile::mul_lower)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v][i] = mfma(cur[k], B[v][s], acc[v][i]);
+            }
+        }
+    }
+    if constexpr (C + 1 < NCH) tri_stream_chunk<NT, UPPER, NV, C + 1>(img, voff, B, acc, ks, nxt);
+}
+
+// acc[v] += T B[v] for the triangular tile image T at `img` (lower, or upper when UPPER)
+template <int NT, bool UPPER, int NV>
+RMH_DEV void tri_stream(const double *img, int lane, const double (&B)[NV][4 * NT], double4_t (&acc)[NV][NT], int ks)
+{
+    const __amdgpu_buffer_rsrc_t r = rsrc(img, (int64_t)TriSeq<NT, UPPER>::N * 64);
+    const uint32_t voff = (uint32_t)lane * 8u;
+    double buf[kStreamChunk];
+    tri_stream_fetch<NT, UPPER, 0>(r, voff, buf);
+    tri_stream_chunk<NT, UPPER, NV, 0>(r, voff, B, acc, ks, buf);
+}
+
 template <int NT>
 struct Tile {
     static constexpr int S = 4 * NT;

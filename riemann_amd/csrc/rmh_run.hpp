@@ -38,17 +38,38 @@ struct Keep {
     }
 };
 
-// v <- T v for a triangular tile image T (lower, or upper when UPPER), in place
+// v <- T v for a triangular tile image T in global memory (lower, or upper when UPPER), in place
 template <int NT, bool UPPER>
-RMH_DEV void tri_apply(const double *img_lane, double (&v)[4 * NT], int ks)
+RMH_DEV void tri_apply(const double *img, int lane, double (&v)[4 * NT], int ks)
 {
     asm volatile("" ::: "memory"); // the image is loop-invariant: keep its loads here (no LICM)
-    double4_t acc[NT];
+    double4_t acc[1][NT];
+    double B[1][4 * NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
-    if (UPPER) Tile<NT>::template mul_upper<true>(img_lane, v, acc, ks);
-    else Tile<NT>::template mul_lower<true>(img_lane, v, acc, ks);
-    Tile<NT>::unpack(acc, v);
+    for (int i = 0; i < NT; ++i) acc[0][i] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4 * NT; ++s) B[0][s] = v[s];
+    tri_stream<NT, UPPER, 1>(img, lane, B, acc, ks);
+    Tile<NT>::unpack(acc[0], v);
+}
+
+// the same for two vectors at once: every slice of the image is loaded once and feeds two MFMAs
+template <int NT, bool UPPER>
+RMH_DEV void tri_apply2(const double *img, int lane, double (&v0)[4 * NT], double (&v1)[4 * NT], int ks)
+{
+    asm volatile("" ::: "memory");
+    double4_t acc[2][NT];
+    double B[2][4 * NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[0][i] = acc[1][i] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4 * NT; ++s) {
+        B[0][s] = v0[s];
+        B[1][s] = v1[s];
+    }
+    tri_stream<NT, UPPER, 2>(img, lane, B, acc, ks);
+    Tile<NT>::unpack(acc[0], v0);
+    Tile<NT>::unpack(acc[1], v1);
 }
 
 // AdaptScaleProposal (riemann/proposals/adaptive.py:11-35) per chain: the adapt()
@@ -241,8 +262,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
                 ufw[s] = thp[s] - rho * th[s];           // randomwalk.py:95-96
                 urv[s] = th[s] - rho * thp[s];
             }
-            tri_apply<NT, false>(pr.Vtiles + lane, ufw, ch.ks);
-            tri_apply<NT, false>(pr.Vtiles + lane, urv, ch.ks);
+            tri_apply2<NT, false>(pr.Vtiles, lane, ufw, urv, ch.ks);
             double sf = 0.0, sr = 0.0;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
@@ -938,7 +958,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
         // keeps the S normals alive (in scratch) across every evaluation
         asm volatile("" : "+v"(k0));
         buf_store(rs_k0(), vo_k0, 0u, k0);
-        if (MASS) tri_apply<NT, false>(pr.chM + lane, p, ch.ks); // p0 = chM xi, :80-81
+        if (MASS) tri_apply<NT, false>(pr.chM, lane, p, ch.ks); // p0 = chM xi, :80-81
         T::load_state(ch.grad, ch.ld, c, g, gr);
 #pragma unroll
         for (int s = 0; s < S; ++s) p[s] = p[s] + heps * gr[s];  // hamiltonian.py:27
@@ -946,8 +966,8 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
             double psc[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) psc[s] = p[s];
-            tri_apply<NT, false>(pr.V + lane, psc, ch.ks);       // M^-1 p = V^T V p, :29
-            tri_apply<NT, true>(pr.VT + lane, psc, ch.ks);
+            tri_apply<NT, false>(pr.V, lane, psc, ch.ks);       // M^-1 p = V^T V p, :29
+            tri_apply<NT, true>(pr.VT, lane, psc, ch.ks);
 #pragma unroll
             for (int s = 0; s < S; ++s) q[s] = q[s] + (eps * pr.minv) * psc[s];
         } else {
@@ -974,8 +994,8 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
                     double psc[S];
 #pragma unroll
                     for (int s = 0; s < S; ++s) psc[s] = p[s];
-                    tri_apply<NT, false>(pr.V + lane, psc, ch.ks);   // :36
-                    tri_apply<NT, true>(pr.VT + lane, psc, ch.ks);
+                    tri_apply<NT, false>(pr.V, lane, psc, ch.ks);   // :36
+                    tri_apply<NT, true>(pr.VT, lane, psc, ch.ks);
 #pragma unroll
                     for (int s = 0; s < S; ++s) q[s] = q[s] + (eps * pr.minv) * psc[s];
                 } else {
@@ -984,7 +1004,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
                 }
             }
         }
-        if (MASS) tri_apply<NT, false>(pr.V + lane, p, ch.ks);   // p = solve(chM, p), :87
+        if (MASS) tri_apply<NT, false>(pr.V, lane, p, ch.ks);   // p = solve(chM, p), :87
         double k1 = 0.0;
 #pragma unroll
         for (int s = 0; s < S; ++s) k1 += p[s] * p[s];
@@ -1115,8 +1135,8 @@ __global__ void __launch_bounds__(64 * NW) k_propose_rw(RwArgs pr, ChainArgs ch,
             ufw[s] = thp[s] - pr.rho * th[s];
             urv[s] = th[s] - pr.rho * thp[s];
         }
-        tri_apply<NT, false>(pr.Vtiles + lane, ufw, ch.ks);
-        tri_apply<NT, false>(pr.Vtiles + lane, urv, ch.ks);
+        tri_apply<NT, false>(pr.Vtiles, lane, ufw, ch.ks);
+        tri_apply<NT, false>(pr.Vtiles, lane, urv, ch.ks);
         double sf = 0.0, sr = 0.0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -1161,15 +1181,15 @@ __global__ void __launch_bounds__(64 * NW) k_propose_hmc(typename M::Args m, Hmc
     double k0 = 0.0;
 #pragma unroll
     for (int s = 0; s < S; ++s) k0 += p[s] * p[s];
-    if (MASS) tri_apply<NT, false>(pr.chM + lane, p, ch.ks);
+    if (MASS) tri_apply<NT, false>(pr.chM, lane, p, ch.ks);
     const double eps = pr.eps, heps = 0.5 * pr.eps;
     auto drift = [&]() {
         if (MASS) {
             double psc[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) psc[s] = p[s];
-            tri_apply<NT, false>(pr.V + lane, psc, ch.ks);
-            tri_apply<NT, true>(pr.VT + lane, psc, ch.ks);
+            tri_apply<NT, false>(pr.V, lane, psc, ch.ks);
+            tri_apply<NT, true>(pr.VT, lane, psc, ch.ks);
 #pragma unroll
             for (int s = 0; s < S; ++s) q[s] = q[s] + (eps * pr.minv) * psc[s];
         } else {
@@ -1191,7 +1211,7 @@ __global__ void __launch_bounds__(64 * NW) k_propose_hmc(typename M::Args m, Hmc
     M::template eval<true>(lds, m, true, lane, q, lpp, gr, parts);
 #pragma unroll
     for (int s = 0; s < S; ++s) p[s] = p[s] + heps * gr[s];
-    if (MASS) tri_apply<NT, false>(pr.V + lane, p, ch.ks);
+    if (MASS) tri_apply<NT, false>(pr.V, lane, p, ch.ks);
     double k1 = 0.0;
 #pragma unroll
     for (int s = 0; s < S; ++s) k1 += p[s] * p[s];

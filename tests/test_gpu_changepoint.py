@@ -1,5 +1,7 @@
 """GPU parity tests of the changepoint model: fixed k (fixtures G5, G13), the generic fused
 kernels on it, and trans-dimensional sampling (fixture G17)."""
+import zlib
+
 import numpy as np
 import pytest
 
@@ -245,7 +247,7 @@ def test_one_lane_per_chain_kernel_search_variants_vs_oracle(ra, orc, case):
     from riemann_amd import workloads as W
     from riemann_amd.models import ChangepointRegression1D
     from riemann_amd.proposals import MetropolisRandomWalk
-    g = np.random.default_rng(hash(case) % 1000)
+    g = np.random.default_rng(zlib.crc32(case.encode()) % 1000)     # (not hash(): salted per process)
     k = 3 if case == "unsorted_k3" else 5
     n = {"n33": 33, "n127_no_padding": 127, "n500_dense": 500}.get(case, 100)
     x, y, truth, cdiag = W.changepoint_data(seed=11, k=k, n=n)
@@ -271,5 +273,7 @@ def test_one_lane_per_chain_kernel_search_variants_vs_oracle(ra, orc, case):
     np.testing.assert_array_equal(s._chain_accept, acc)
     np.testing.assert_allclose(s._chain_thetas, ht, rtol=RTOL, atol=1e-12)
     fin = np.isfinite(hl)
-    np.testing.assert_allclose(s._chain_logpost[fin], hl[fin], rtol=RTOL)
+    # the log posterior of these chains passes through zero (terms of size ~10 cancel): a relative
+    # bound alone fails by chance on a value of 1e-4 (seen: 5e-10 relative = 5e-14 absolute)
+    np.testing.assert_allclose(s._chain_logpost[fin], hl[fin], rtol=RTOL, atol=1e-11)
     assert 0.01 < acc.mean() < 0.95

@@ -160,6 +160,14 @@ RMH_DEV void tri_stream(const double *img, int lane, const double (&B)[NV][4 * N
     tri_stream_chunk<NT, UPPER, NV, 0>(r, voff, B, acc, ks, buf);
 }
 
+// one right-hand side: acc += T B
+template <int NT, bool UPPER>
+RMH_DEV void tri_stream1(const double *img, int lane, const double (&B)[4 * NT], double4_t (&acc)[NT], int ks)
+{
+    tri_stream<NT, UPPER, 1>(img, lane, reinterpret_cast<const double (&)[1][4 * NT]>(B),
+                             reinterpret_cast<double4_t (&)[1][NT]>(acc), ks);
+}
+
 template <int NT>
 struct Tile {
     static constexpr int S = 4 * NT;
@@ -172,9 +180,7 @@ struct Tile {
     // acc[i] += sum_{s <= 4i+3} A_lo(i,s) * B[s]     (A = lower-triangular image)
     // k-steps s >= ks = ceil(d/4) carry B[s] = 0 (padding coordinates) and are
     // skipped: only the last four can be, a wave-uniform test each.
-    // FENCE: pin the schedule every other k-step (images read from global memory:
-    // unfenced, the scheduler issues all ~110 loads of a product up front = 220 VGPRs).
-    template <bool FENCE = false>
+    // (img_lane points into LDS; images in global memory go through tri_stream)
     static RMH_DEV void mul_lower(const double *img_lane, const double (&B)[S], double4_t (&acc)[NT],
                                   int ks)
     {
@@ -185,12 +191,10 @@ struct Tile {
                 for (int i = s / 4; i < NT; ++i)
                     acc[i] = mfma(img_lane[lo(i, s) * 64], B[s], acc[i]);
             }
-            if (FENCE && (s & 1)) __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     // acc[i] += sum_{s >= 4i} A_up(i,s) * B[s]       (A = upper-triangular image)
-    template <bool FENCE = false>
     static RMH_DEV void mul_upper(const double *img_lane, const double (&B)[S], double4_t (&acc)[NT],
                                   int ks)
     {
@@ -201,7 +205,6 @@ struct Tile {
                 for (int i = 0; i <= s / 4; ++i)
                     acc[i] = mfma(img_lane[up(i, s) * 64], B[s], acc[i]);
             }
-            if (FENCE && (s & 1)) __builtin_amdgcn_sched_barrier(0);
         }
     }
 

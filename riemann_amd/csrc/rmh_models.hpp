@@ -133,7 +133,7 @@ struct MixModel {
         }
         for (int k = 0; k < m.ncomp; ++k) {
             asm volatile("" ::: "memory");
-            const double *W = m.Wtiles + (size_t)k * kImg + lane;
+            const double *W = m.Wtiles + (size_t)k * kImg;
             const double *mu = m.mu_pad + (size_t)k * (4 * S);
             double y[S];
 #pragma unroll
@@ -141,7 +141,7 @@ struct MixModel {
             double4_t a[NT];
 #pragma unroll
             for (int i = 0; i < NT; ++i) a[i] = double4_t{0.0, 0.0, 0.0, 0.0};
-            T::template mul_lower<true>(W, y, a, m.ks);
+            tri_stream1<NT, false>(W, lane, y, a, m.ks);
             double uu = 0.0;
 #pragma unroll
             for (int i = 0; i < NT; ++i)
@@ -156,7 +156,7 @@ struct MixModel {
                 double4_t v[NT];
 #pragma unroll
                 for (int i = 0; i < NT; ++i) v[i] = double4_t{0.0, 0.0, 0.0, 0.0};
-                T::template mul_upper<true>(m.WTtiles + (size_t)k * kImg + lane, u, v, m.ks);
+                tri_stream1<NT, true>(m.WTtiles + (size_t)k * kImg, lane, u, v, m.ks);
                 double gk[S];
                 T::unpack(v, gk);
 #pragma unroll

@@ -53,6 +53,14 @@ RMH_DEV void tri_apply(const double *img, int lane, double (&v)[4 * NT], int ks)
     Tile<NT>::unpack(acc[0], v);
 }
 
+// acc += L xi for the proposal's image in LDS, or in global memory when GLOBAL
+template <int NT, bool GLOBAL>
+RMH_DEV void mul_lower_any(const double *img, int lane, const double (&B)[4 * NT], double4_t (&acc)[NT], int ks)
+{
+    if constexpr (GLOBAL) tri_stream1<NT, false>(img, lane, B, acc, ks);
+    else Tile<NT>::mul_lower(img + lane, B, acc, ks);
+}
+
 // the same for two vectors at once: every slice of the image is loaded once and feeds two MFMAs
 template <int NT, bool UPPER>
 RMH_DEV void tri_apply2(const double *img, int lane, double (&v0)[4 * NT], double (&v1)[4 * NT], int ks)
@@ -254,7 +262,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
 #pragma unroll
             for (int s = 0; s < S; ++s) thp[s] = rho * th[s];
             T::pack(thp, acc);
-            T::template mul_lower<LGLOBAL>(Limg + lane, xi, acc, ch.ks);   // image holds rho_c * L
+            mul_lower_any<NT, LGLOBAL>(Limg, lane, xi, acc, ch.ks);   // image holds rho_c * L
             T::unpack(acc, thp);
             double ufw[S], urv[S];
 #pragma unroll
@@ -273,13 +281,13 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
         } else if (ADAPT && !PCN) { // the chain's own adapted scale: theta + scale * (L xi), image unscaled
 #pragma unroll
             for (int i = 0; i < NT; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
-            T::template mul_lower<LGLOBAL>(Limg + lane, xi, acc, ch.ks);
+            mul_lower_any<NT, LGLOBAL>(Limg, lane, xi, acc, ch.ks);
             T::unpack(acc, thp);
 #pragma unroll
             for (int s = 0; s < S; ++s) thp[s] = th[s] + ad.scale * thp[s];
         } else {
             T::pack(th, acc);
-            T::template mul_lower<LGLOBAL>(Limg + lane, xi, acc, ch.ks);
+            mul_lower_any<NT, LGLOBAL>(Limg, lane, xi, acc, ch.ks);
             T::unpack(acc, thp);
         }
         M::template eval<false>(mlds, m, false, lane, thp, lpp, dummy, parts);

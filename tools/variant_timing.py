@@ -2,7 +2,10 @@
 (device timer) — the variants that are not a BASELINE config (pCN, mass-matrix HMC, adapted scales,
 tempering) beside the plain random walk / HMC they share their kernels' structure with.
 
-    python tools/variant_timing.py [--json out.json] [d ...]          (default d = 100 96 36)
+    python tools/variant_timing.py [--json out.json] [--model gauss|logreg|mixture] [d ...]   (default d = 100 96 36)
+
+--model logreg: logistic regression on 1000 x d synthetic rows (a small data term, so that what the
+proposal adds shows); mixture: two Gaussian components.
 """
 import json
 import os
@@ -32,18 +35,29 @@ def variants(model, C):
     ]
 
 
-def one(d, chains=65536):
+def one(d, kind="gauss", chains=65536):
     rng = np.random.default_rng(d)
     A = rng.standard_normal((d, d)) / np.sqrt(d)
     C = A @ A.T + np.eye(d)
-    model = ra.models.MultiGaussianDist(np.zeros(d), C)
+    div = 1
+    if kind == "gauss":
+        model = ra.models.MultiGaussianDist(np.zeros(d), C)
+    elif kind == "mixture":
+        model = ra.models.MixtureDist([[0.3, ra.models.MultiGaussianDist(np.full(d, -0.5), C)],
+                                       [0.7, ra.models.MultiGaussianDist(np.full(d, 0.5), C)]])
+    else:
+        from riemann_amd.workloads import logreg_data
+        X, y = logreg_data(1000, d)[:2]
+        model = ra.models.LogisticRegression(X, y)
+        C, div = 0.01 * C, 4
     rows = []
     for name, make, its in variants(model, C):
+        its = max(its // div, 10)
         s = ra.Sampler(model, make(), np.zeros((chains, d)), seed=1)
         s.run(its, record=False)
         s.run(its, record=False)
         ms = s.last_run_ms / its
-        rows.append({"d": d, "variant": name, "ms_per_iteration": ms})
+        rows.append({"d": d, "model": kind, "variant": name, "ms_per_iteration": ms})
         print("d=%4d  %-26s %8.4f ms / iteration" % (d, name, ms), flush=True)
     return rows
 
@@ -53,9 +67,12 @@ if __name__ == "__main__":
     out = None
     if args and args[0] == "--json":
         out, args = args[1], args[2:]
+    kind = "gauss"
+    if args and args[0] == "--model":
+        kind, args = args[1], args[2:]
     rows = []
     for d in [int(a) for a in args] or [100, 96, 36]:
-        rows += one(d)
+        rows += one(d, kind)
     if out:
         with open(out, "w") as f:
             json.dump({"chains": 65536, "recorded": False, "rows": rows}, f, indent=1)

@@ -169,6 +169,9 @@ int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
  * the uniform's word is NOT drawn), in the order and with the bits the fused kernels use.  For the mixed-plugin path: a Python Model or Proposal next to
  * device ones runs sampler.py:72-90 on the host with THIS stream. */
 int rmh_rng_draw(uint64_t *rng, int64_t N, int d, int T, double *xi, double *u);
+/* the same in a given normal mode (0: as rmh_rng_draw; 1: the 64-bit-resolution mode of
+ * rmh_state_set_normal_mode, ceil(d/4) words per sub-stream and vector) */
+int rmh_rng_draw_mode(uint64_t *rng, int64_t N, int d, int T, int normal_mode, double *xi, double *u);
 
 
 /* ---- chain state (device resident; survives between run() calls as the
@@ -181,6 +184,15 @@ int rmh_state_set_theta(rmh_state_t s, const double *theta);
 int rmh_state_get(rmh_state_t s, double *theta, double *logpost); /* current_state(), :56-60 */
 int rmh_state_get_rng(rmh_state_t s, uint64_t *rng);   /* (N,16) */
 int rmh_state_set_rng(rmh_state_t s, const uint64_t *rng);
+/* Resolution of the chains' standard normals (np.random.normal of proposals/randomwalk.py:25 and
+ * proposals/hamiltonian.py:79 draws float64 values).  mode 0 (default): two normals per 64-bit stream
+ * word, each the quantile of a 32-bit half word (a lattice of 2^-27 in p inside a cell, |z| <= 6.4);
+ * mode 1: ONE normal per word -- 52 bits inside a cell, p down to 2^-58 (|z| <= 8.6), the quantile map
+ * good to 2.1e-16 -- at twice the stream words and a longer table evaluation; served by the generic
+ * kernels (the d = 16 NF + 1..4 tail kernels, the specialised changepoint kernels, d > 112 and the
+ * variable-k model are 32-bit only: the first two are routed around, the last two refuse). */
+int rmh_state_set_normal_mode(rmh_state_t s, int mode);
+int rmh_state_get_normal_mode(rmh_state_t s, int *mode);
 int rmh_state_get_adapt(rmh_state_t s, double *adapt);       /* (N,3) */
 int rmh_state_set_adapt(rmh_state_t s, const double *adapt);
 /* the auxiliary per-chain value of an adaptive proposal, (N) float64: AdaptScalepCN's
@@ -298,6 +310,8 @@ int rmh_allgather_history(rmh_history_t h, int64_t e0, int64_t e1, int64_t strid
  * chain0..chain0+N-1, generated on the device */
 int rmh_debug_rng_stream(uint64_t seed, uint64_t chain0, int64_t N, int d, int T,
                          double *xi, double *u);
+int rmh_debug_rng_stream_mode(uint64_t seed, uint64_t chain0, int64_t N, int d, int T, int normal_mode,
+                              double *xi, double *u);
 /* D = A(16x4) B(4x16) + C(16x16) through one v_mfma_f64_16x16x4_f64, row-major in/out */
 int rmh_debug_mfma(const double *A, const double *B, const double *C, double *D);
 

@@ -47,6 +47,10 @@ def lib():
     L.orc_log.argtypes = [dbl]
     L.orc_normal_from_half.restype = dbl
     L.orc_normal_from_half.argtypes = [C.c_uint32]
+    L.orc_normal_from_word.restype = dbl
+    L.orc_normal_from_word.argtypes = [u64]
+    L.orc_set_normal_mode.argtypes = [i32]
+    L.orc_get_normal_mode.restype = i32
     L.orc_rng_seed.argtypes = [u64, u64, i64, _u64p]
     L.orc_rng_stream.argtypes = [_u64p, i64, i32, i32, _f64p, _f64p]
     L.orc_model_gaussian.restype = vp
@@ -141,6 +145,30 @@ def rng_pt_stream(state, d, T):
 
 def olog(x):
     return lib().orc_log(float(x))
+
+
+def normal_from_word(w):
+    """one normal from one 64-bit stream word (the 64-bit-resolution normal mode)"""
+    return lib().orc_normal_from_word(int(w))
+
+
+class normal_mode:
+    """with oracle.normal_mode("f64"): every draw of normals inside uses ONE 64-bit word per normal
+    (Sampler(..., normals="f64") of the product); "f32x2" is the default stream."""
+
+    def __init__(self, mode):
+        if mode not in ("f32x2", "f64"):
+            raise ValueError("normal mode is 'f32x2' or 'f64'")
+        self.mode = 1 if mode == "f64" else 0
+
+    def __enter__(self):
+        self.prev = lib().orc_get_normal_mode()
+        lib().orc_set_normal_mode(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_normal_mode(self.prev)
+        return False
 
 
 def normal_from_half(h):

@@ -170,10 +170,51 @@ double orc_normal_from_half(uint32_t h)
 
 #define ORC_2M53 0x1p-53
 
+/* ---- the 64-bit-resolution normal mode (Sampler(..., normals="f64")): ONE normal per word ----
+ *   sign = x & 1;  q = x | 1;  r = min(clz64(q), 55);  N = (q << r) | 2^63
+ *   cell = 8 r + N[62:60];  v = 1 + N[59:8] 2^-52;  t = 2 v - 3 in [-1, 1)
+ *   z = Horner_fma(cell polynomial of degree 10 in t), negated when sign is set
+ * the tail probability p = 2^(-2-r) (1 + (cell + (t+1)/2)/8) on a lattice of 2^-57-r.. in p (52 bits inside a
+ * cell while the word has them), out to p = 2^-58 (|z| = 8.6), through a map good to 2.1e-16
+ * (oracle/rmh_icdf64_table.h, tools/gen_icdf_table.py --f64): what numpy's float64 normals offer the
+ * reference (proposals/randomwalk.py:25, hamiltonian.py:79).  Word s of sub-stream g is coordinate 4s+g;
+ * every sub-stream draws ceil(d/4) words per vector of normals. */
+#include "rmh_icdf64_table.h"
+static int g_normal_mode = 0; /* 0: two normals per word (v4, above); 1: one normal per word */
+
+void orc_set_normal_mode(int mode) { g_normal_mode = mode ? 1 : 0; }
+int orc_get_normal_mode(void) { return g_normal_mode; }
+
+double orc_normal_from_word(u64 x)
+{
+    const u64 q = x | 1ULL;
+    int r = __builtin_clzll(q);
+    if (r > RMH_ICDF64_ROWS - 1) r = RMH_ICDF64_ROWS - 1;
+    const u64 N = (q << r) | 0x8000000000000000ULL;
+    const int j = (int)(N >> 60) & 7;
+    const u64 mant = (N >> 8) & 0x000FFFFFFFFFFFFFULL;
+    const double v = 1.0 + (double)mant * 0x1p-52; /* exact: mant < 2^52 */
+    const double t = fma(2.0, v, -3.0);
+    const double *c = rmh_icdf64_table + (size_t)(r * RMH_ICDF64_SUB + j) * RMH_ICDF64_NC;
+    double z = c[RMH_ICDF64_NC - 1];
+    for (int k = RMH_ICDF64_NC - 2; k >= 0; k--) z = fma(z, t, c[k]);
+    return (x & 1ULL) ? -z : z;
+}
+
 /* d normals for one chain; st = 16 words [g][4].  Every sub-stream draws M = ceil(d/8)
- * words; the high half of word m of sub-stream g is coordinate 8m+g, the low half 8m+4+g. */
+ * words; the high half of word m of sub-stream g is coordinate 8m+g, the low half 8m+4+g.
+ * (64-bit mode: ceil(d/4) words, word s of sub-stream g is coordinate 4s+g) */
 void orc_rng_normals(u64 *st, int d, double *xi)
 {
+    if (g_normal_mode) {
+        const int ks = (d + 3) / 4;
+        for (int g = 0; g < 4; g++)
+            for (int s = 0; s < ks; s++) {
+                const double z = orc_normal_from_word(orc_next(st + 4 * g));
+                if (4 * s + g < d) xi[4 * s + g] = z;
+            }
+        return;
+    }
     const int M = (d + 7) / 8;
     for (int g = 0; g < 4; g++)
         for (int m = 0; m < M; m++) {

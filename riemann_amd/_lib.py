@@ -11,6 +11,16 @@ import numpy as np
 
 from .sampling_errors import ParameterError
 
+# Sampler(..., normals=...): resolution of the stream's standard normals (rmh_state_set_normal_mode)
+NORMAL_MODES = {"f32x2": 0, "f64": 1}
+
+
+def normal_mode(name):
+    if name not in NORMAL_MODES:
+        raise ParameterError("normals must be 'f32x2' (two normals per stream word, the default) or 'f64' "
+                             "(one per word), not {!r}".format(name))
+    return NORMAL_MODES[name]
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("RIEMANN_HIP_LIB") or os.path.join(_HERE, "csrc", "libriemann_hip.so")
 
@@ -57,6 +67,9 @@ SIGNATURES = {
     "rmh_proposal_free": [_vp],
     "rmh_propose": [_vp, _vp, _f64, _i64, _u64, _f64, _f64],
     "rmh_rng_draw": [_u64, _i64, _int, _int, _vp, _vp],
+    "rmh_rng_draw_mode": [_u64, _i64, _int, _int, _int, _vp, _vp],
+    "rmh_state_set_normal_mode": [_vp, _int],
+    "rmh_state_get_normal_mode": [_vp, _vp],
     "rmh_state_create": [_vp, _i64, _u64s, _u64s, _pvp],
     "rmh_state_set_theta": [_vp, _f64],
     "rmh_state_get": [_vp, _vp, _vp],
@@ -90,6 +103,7 @@ SIGNATURES = {
     "rmh_allgather_samples": [_vp, _f64],
     "rmh_allreduce_moments": [_vp, _f64],
     "rmh_debug_rng_stream": [_u64s, _u64s, _i64, _int, _int, _f64, _f64],
+    "rmh_debug_rng_stream_mode": [_u64s, _u64s, _i64, _int, _int, _int, _f64, _f64],
     "rmh_history_reduce_sums": [_vp, _i64, _i64, _int, _vp, _vp, _vp],
     "rmh_history_moments": [_vp, _i64, _i64, _f64],
     "rmh_allgather_history": [_vp, _i64, _i64, _i64, _f64],

@@ -6,6 +6,7 @@
 // (Sampler.run / PTSampler.run and the covariance adaptation: rmh_run_api.hip.)
 #include "rmh_host.hpp"
 #include "rmh_icdf_table.h"
+#include "rmh_icdf64_table.h"
 #include "rmh_logistic_table.h"
 
 using namespace rmh;
@@ -25,7 +26,8 @@ hipStream_t g_copy = nullptr;                         // device -> host copies o
 hipEvent_t g_cp_ready[2] = {nullptr, nullptr}, g_cp_done[2] = {nullptr, nullptr};
 int g_last_launches = 0;
 bool g_timed = false;
-double *g_icdf = nullptr; // device copy of the inverse-CDF table, 12-double cell stride
+double *g_icdf = nullptr;   // device copy of the inverse-CDF table in its LDS layout
+double *g_icdf64 = nullptr; // the 64-bit normal mode's table
 double *g_logi = nullptr; // device copy of the logistic link-function table
 
 int fail(int code, const std::string &msg)
@@ -112,7 +114,8 @@ ChainArgs chain_args(const rmh_state *s)
     c.dp = s->dp;
     c.ks = s->ks;
     c.M = (s->d + 7) / 8;   // stream words per sub-stream per iteration: two normals each
-    c.icdf = g_icdf;
+    c.nmode = s->nmode;
+    c.icdf = s->nmode ? g_icdf64 : g_icdf;
     return c;
 }
 
@@ -363,6 +366,15 @@ int rmh_init(int device)
                         rmh_icdf_table[(r * RMH_ICDF_SUB + j) * RMH_ICDF_NC + k];
         int rc = upload(&g_icdf, pad.data(), pad.size());
         if (rc) return rc;
+        // the 64-bit normal mode's table: kIcdf64Stride, kIcdf64RowStride of rmh_device.hpp
+        static_assert(RMH_ICDF64_ROWS == 56 && RMH_ICDF64_SUB == 8 && RMH_ICDF64_NC == 11, "table shape");
+        const int cs64 = 12, rs64 = RMH_ICDF64_SUB * cs64 + 2;
+        std::vector<double> pad64((size_t)RMH_ICDF64_ROWS * rs64, 0.0);
+        for (int r = 0; r < RMH_ICDF64_ROWS; ++r)
+            for (int j = 0; j < RMH_ICDF64_SUB; ++j)
+                for (int k = 0; k < RMH_ICDF64_NC; ++k)
+                    pad64[(size_t)r * rs64 + j * cs64 + k] = rmh_icdf64_table[(r * RMH_ICDF64_SUB + j) * RMH_ICDF64_NC + k];
+        if ((rc = upload(&g_icdf64, pad64.data(), pad64.size()))) return rc;
         static_assert(RMH_LOGI_NI == 600 && RMH_LOGI_W == 16 && RMH_LOGI_NC == 6, "table shape");
         if ((rc = upload(&g_logi, rmh_logistic_table, sizeof(rmh_logistic_table) / sizeof(double)))) return rc;
     }
@@ -1153,6 +1165,25 @@ int ensure_adapt(rmh_state *s)
 
 extern "C" {
 
+// Sampler(..., normals="f64"): the chains' normals come one per 64-bit stream word (rmh_device.hpp); 0 = the
+// default, two per word.  A property of the state: every run / evaluation of these chains uses it.
+int rmh_state_set_normal_mode(rmh_state_t s, int mode)
+{
+    RMH_NEED_INIT();
+    if (!s || (mode != 0 && mode != 1)) return fail(RMH_ERR_PARAM, "state_set_normal_mode: mode is 0 or 1");
+    if (mode && (s->m->big || s->m->kind == kChangepointRJ))
+        return fail(RMH_ERR_PARAM, "normals=\"f64\" is not built for d > 112 or the variable-k changepoint model");
+    s->nmode = mode;
+    return RMH_OK;
+}
+
+int rmh_state_get_normal_mode(rmh_state_t s, int *mode)
+{
+    if (!s || !mode) return fail(RMH_ERR_PARAM, "state_get_normal_mode: null argument");
+    *mode = s->nmode;
+    return RMH_OK;
+}
+
 int rmh_state_get_adapt(rmh_state_t s, double *adapt)
 {
     RMH_NEED_INIT();
@@ -1483,8 +1514,13 @@ extern "C" {
 // (sampler.py:84) -- exactly as the fused kernels consume them.  d = 0: the uniforms only.
 int rmh_rng_draw(uint64_t *rng, int64_t N, int d, int T, double *xi, double *u)
 {
+    return rmh_rng_draw_mode(rng, N, d, T, 0, xi, u);
+}
+
+int rmh_rng_draw_mode(uint64_t *rng, int64_t N, int d, int T, int normal_mode, double *xi, double *u)
+{
     RMH_NEED_INIT();
-    if (!rng || N < 1 || d < 0 || T < 1 || (d > 0 && !xi) || (d == 0 && !u))
+    if (!rng || N < 1 || d < 0 || T < 1 || (d > 0 && !xi) || (d == 0 && !u) || (normal_mode != 0 && normal_mode != 1))
         return fail(RMH_ERR_PARAM, "rng_draw: bad argument");
     const int64_t ld = pad16(N);
     std::vector<uint64_t> dev;
@@ -1497,7 +1533,7 @@ int rmh_rng_draw(uint64_t *rng, int64_t N, int d, int T, double *xi, double *u)
         (void)hipFree(drng); (void)hipFree(dxi); (void)hipFree(du);
         return rc;
     }
-    hipError_t e = launch_rng_stream(drng, ld, d, T, g_icdf, dxi, du, g_stream);
+    hipError_t e = launch_rng_stream(drng, ld, d, T, normal_mode ? g_icdf64 : g_icdf, normal_mode, dxi, du, g_stream);
     if (e == hipSuccess && d > 0)
         e = hipMemcpy2DAsync(xi, (size_t)N * d * 8, dxi, (size_t)ld * d * 8, (size_t)N * d * 8, (size_t)T,
                              hipMemcpyDeviceToHost, g_stream);
@@ -1515,8 +1551,14 @@ int rmh_rng_draw(uint64_t *rng, int64_t N, int d, int T, double *xi, double *u)
 // --------------------------------------------------------------- test hooks
 int rmh_debug_rng_stream(uint64_t seed, uint64_t chain0, int64_t N, int d, int T, double *xi, double *u)
 {
+    return rmh_debug_rng_stream_mode(seed, chain0, N, d, T, 0, xi, u);
+}
+
+int rmh_debug_rng_stream_mode(uint64_t seed, uint64_t chain0, int64_t N, int d, int T, int normal_mode, double *xi,
+                              double *u)
+{
     RMH_NEED_INIT();
-    if (N < 1 || d < 1 || T < 1) return fail(RMH_ERR_PARAM, "bad argument");
+    if (N < 1 || d < 1 || T < 1 || (normal_mode != 0 && normal_mode != 1)) return fail(RMH_ERR_PARAM, "bad argument");
     const int64_t ld = pad16(N);
     uint64_t *rng = nullptr;
     double *dxi = nullptr, *du = nullptr;
@@ -1527,7 +1569,8 @@ int rmh_debug_rng_stream(uint64_t seed, uint64_t chain0, int64_t N, int d, int T
         return rc;
     }
     hipError_t e = launch_rng_seed(rng, ld, seed, chain0, g_stream);
-    if (e == hipSuccess) e = launch_rng_stream(rng, ld, d, T, g_icdf, dxi, du, g_stream);
+    if (e == hipSuccess)
+        e = launch_rng_stream(rng, ld, d, T, normal_mode ? g_icdf64 : g_icdf, normal_mode, dxi, du, g_stream);
     if (e == hipSuccess)
         e = hipMemcpy2DAsync(xi, (size_t)N * d * 8, dxi, (size_t)ld * d * 8, (size_t)N * d * 8, (size_t)T,
                              hipMemcpyDeviceToHost, g_stream);

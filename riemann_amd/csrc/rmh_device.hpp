@@ -302,9 +302,64 @@ constexpr int kIcdfRows = 32, kIcdfSub = 8, kIcdfNC = 7, kIcdfStride = 10;
 constexpr int kIcdfRowStride = kIcdfSub * kIcdfStride;            // doubles
 constexpr int kIcdfDoubles = kIcdfRows * kIcdfRowStride;          // 2560 = 20 480 B
 
-RMH_DEV void icdf_stage(double *lds_tab, const double *glb_tab)
+// The 64-bit-resolution normal mode (Sampler(..., normals="f64"); ChainArgs::nmode = 1): ONE normal per
+// stream word,
+//   sign = x & 1;  q = x | 1;  r = min(clz64(q), 55);  N = (q << r) | 2^63
+//   cell = 8 r + N[62:60];  v = 1 + N[59:8] 2^-52;  t = 2 v - 3;  z = Horner_fma(degree 10 in t)
+// 52 bits inside a cell, p down to 2^-58 (|z| <= 8.6), the map good to 2.1e-16 -- the resolution of the
+// float64 normals numpy hands the reference (randomwalk.py:25).  Its table (56 rows, 11 coefficients in
+// a 12-double cell, rows 2 doubles longer than their cells so that rows r and r+1 sit on disjoint banks:
+// 43 904 B) takes the place of the 32-bit one in LDS; word s of sub-stream g is coordinate 4s+g.
+// Served by the generic kernels (k_run_rw, k_run_hmc, the stand-alone proposals, rmh_rng_draw); the
+// launchers route around the kernels whose stream length is a compile-time fact.
+constexpr int kIcdf64Rows = 56, kIcdf64NC = 11, kIcdf64Stride = 12;
+constexpr int kIcdf64RowStride = kIcdfSub * kIcdf64Stride + 2;    // doubles
+constexpr int kIcdf64Doubles = kIcdf64Rows * kIcdf64RowStride;    // 5488 = 43 904 B
+
+constexpr __host__ __device__ int icdf_doubles(int nmode) { return nmode ? kIcdf64Doubles : kIcdfDoubles; }
+
+RMH_DEV void icdf_stage(double *lds_tab, const double *glb_tab, int nmode = 0)
 {
-    for (int i = threadIdx.x; i < kIcdfDoubles; i += blockDim.x) lds_tab[i] = glb_tab[i];
+    const int n = icdf_doubles(nmode);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lds_tab[i] = glb_tab[i];
+}
+
+// N normals of the 64-bit mode in lockstep (see normals_lockstep below)
+template <int N>
+RMH_DEV void normals64_lockstep(const uint64_t (&w)[N], const double *tab, double (&z)[N])
+{
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    double t[N];
+    const d2_t *c[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint64_t q = w[i] | 1ULL;
+        int r = __builtin_clzll(q);
+        r = r > kIcdf64Rows - 1 ? kIcdf64Rows - 1 : r;
+        const uint64_t Nn = (q << r) | 0x8000000000000000ULL;
+        const int j = (int)(Nn >> 60) & 7;
+        const uint64_t mant = (Nn >> 8) & 0x000FFFFFFFFFFFFFULL;
+        const double v = __longlong_as_double((long long)(0x3FF0000000000000ULL | mant));
+        t[i] = fma_(2.0, v, -3.0);
+        c[i] = static_cast<const d2_t *>(__builtin_assume_aligned(tab + r * kIcdf64RowStride + j * kIcdf64Stride, 16));
+    }
+    d2_t a[N][6];
+#pragma unroll
+    for (int k = 5; k >= 0; --k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) a[i][k] = c[i][k];
+#pragma unroll
+    for (int i = 0; i < N; ++i) z[i] = a[i][5].x;
+#pragma unroll
+    for (int k = 4; k >= 0; --k) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) z[i] = fma_(z[i], t[i], a[i][k].y);
+#pragma unroll
+        for (int i = 0; i < N; ++i) z[i] = fma_(z[i], t[i], a[i][k].x);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        z[i] = __longlong_as_double(__double_as_longlong(z[i]) ^ ((long long)(w[i] & 1ULL) << 63));
 }
 
 // N normals in lockstep (the halves of one or two stream words): all cells' table reads first,

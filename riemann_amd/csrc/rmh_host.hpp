@@ -80,6 +80,7 @@ struct rmh_state {
     double *last_theta = nullptr, *last_logpost = nullptr;
     uint64_t *rng = nullptr;
     bool valid = false, grad_valid = false;
+    int nmode = 0; // 1: the 64-bit-resolution normal mode (rmh_state_set_normal_mode)
 };
 
 struct rmh_history {
@@ -102,7 +103,8 @@ extern hipStream_t g_copy;
 extern hipEvent_t g_cp_ready[2], g_cp_done[2];
 extern int g_last_launches;
 extern bool g_timed;
-extern double *g_icdf; // device copy of the inverse-CDF table, 12-double cell stride
+extern double *g_icdf;   // device copy of the inverse-CDF table in its LDS layout (rmh_device.hpp)
+extern double *g_icdf64; // the 64-bit normal mode's table, likewise
 extern double *g_logi; // device copy of the logistic link-function table
 
 int fail(int code, const std::string &msg);

@@ -100,7 +100,8 @@ struct ChainArgs {
     int dp;             // rows of theta/grad: 16*NT (MFMA kernels)
     int ks;             // ceil(d/4): history entries hold 4*ks rows
     int M;              // 64-bit words per sub-stream per iteration: ceil(d/8), two normals per word
-    const double *icdf; // inverse-normal-CDF table, 96-byte cell stride (rmh_device.hpp)
+    const double *icdf; // inverse-normal-CDF table in its LDS layout (rmh_device.hpp): the 32-bit one, or the 64-bit mode's
+    int nmode;          // 0: two normals per stream word; 1: one normal per word (Sampler(..., normals="f64"))
     double *adapt;      // AdaptScaleProposal state, 3 rows of ld: Nsamples, Naccepts, scale; or null
     double adapt_target;
 };
@@ -254,7 +255,7 @@ hipError_t launch_hist_reduce(const double *hist, int64_t e0, int64_t e1, int ro
                               hipStream_t st);
 hipError_t launch_rng_seed(uint64_t *rng, int64_t ld, uint64_t seed, uint64_t chain0,
                            hipStream_t st);
-hipError_t launch_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const double *icdf,
+hipError_t launch_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const double *icdf, int nmode,
                              double *xi, double *u, hipStream_t st);
 hipError_t launch_transpose_nd_to_dn(const double *src, double *dst, int64_t N, int d,
                                      int64_t ld, hipStream_t st);

@@ -1713,7 +1713,7 @@ static hipError_t cp_generic_launch(const CpArgs &m, const RwArgs &p, const Chai
 {
     using M = CpPolicy<KC>;
     if (m.n > kCpPolicyMaxN) return hipErrorInvalidValue;
-    const size_t lds = sizeof(double) * (tri_tiles(M::NT) * 64 + M::lds_doubles(false) + kIcdfDoubles);
+    const size_t lds = sizeof(double) * (tri_tiles(M::NT) * 64 + M::lds_doubles(false) + icdf_doubles(c.nmode));
     const dim3 grid((unsigned)((c.nblocks + 3) / 4)), block(256);
     hipError_t e = hipSuccess;
 #define RMH_CP_GEN(...)                                                                          \

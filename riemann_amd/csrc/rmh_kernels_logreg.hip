@@ -29,7 +29,7 @@ hipError_t launch_logreg_rw(int NT, const LogRegArgs &m, const RwArgs &p, const 
 {
     RMH_NT_DISPATCH(NT, {
         using M = LogRegModel<kNT>;
-        const size_t lds = sizeof(double) * (M::lds_doubles(false) + kIcdfDoubles);
+        const size_t lds = sizeof(double) * (M::lds_doubles(false) + icdf_doubles(c.nmode));
         if (r.pt_K > 0)
             return launch(k_run_rw<M, 4, false, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
         if (adapt)
@@ -43,7 +43,7 @@ hipError_t launch_logreg_pcn(int NT, const LogRegArgs &m, const RwArgs &p, const
 {
     RMH_NT_DISPATCH(NT, {
         using M = LogRegModel<kNT>;
-        const size_t lds = sizeof(double) * (M::lds_doubles(false) + kIcdfDoubles);
+        const size_t lds = sizeof(double) * (M::lds_doubles(false) + icdf_doubles(c.nmode));
         if (r.pt_K > 0) return launch(k_run_rw<M, 4, false, true, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
         if (adapt) return launch(k_run_rw<M, 4, true, true, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
         return launch(k_run_rw<M, 4, false, true, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
@@ -55,7 +55,7 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
 {
     RMH_NT_DISPATCH(NT, {
         using M = LogRegModel<kNT>;
-        const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
+        const size_t lds = sizeof(double) * (M::lds_doubles(true) + icdf_doubles(c.nmode));
         // d > 64: eight waves per workgroup (two per SIMD, <= 256 registers each).  The
         // second wave cannot overlap VALU with MFMA on this chip, but it fills the
         // s_waitcnt / barrier gaps of the stage loop: 0.52 -> 0.61 of the FP64 roof,
@@ -66,7 +66,7 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
         // Eight waves for every dimension; sixteen at d <= 16 spill 100 registers at the 128 cap.)
         constexpr int NW = 8;
         if constexpr (kNT >= 2) { // d = 16 NF + 1 .. 16 NF + 4: the last column tile of the gradient on the VALU (rmh_models.hpp)
-            if (m.ks == 4 * (kNT - 1) + 1 && r.pt_K == 0 && !p.chM && !policy(RMH_POLICY_NO_TAIL)) {
+            if (m.ks == 4 * (kNT - 1) + 1 && r.pt_K == 0 && !p.chM && !c.nmode && !policy(RMH_POLICY_NO_TAIL)) {
                 using MT = LogRegModel<(kNT >= 2 ? kNT : 2), true>;   // (kNT = 1 never gets here; the launcher is not a template)
                 if (adapt) return launch(k_run_hmc<MT, NW, true, false>, c.nblocks, NW, lds, st, m, p, c, r);
                 return launch(k_run_hmc<MT, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);
@@ -91,7 +91,7 @@ hipError_t launch_logreg_propose_hmc(int NT, const LogRegArgs &m, const HmcArgs 
 {
     RMH_NT_DISPATCH(NT, {
         using M = LogRegModel<kNT>;
-        const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
+        const size_t lds = sizeof(double) * (M::lds_doubles(true) + icdf_doubles(c.nmode));
         if (p.chM) return launch(k_propose_hmc<M, 4, true>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
         return launch(k_propose_hmc<M, 4, false>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
     })

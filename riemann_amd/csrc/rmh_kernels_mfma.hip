@@ -29,7 +29,7 @@ hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const Ch
 {
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
-        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false) + kIcdfDoubles);
+        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false) + icdf_doubles(c.nmode));
         // d > 64: the two tile images fill the LDS of a CU, so one workgroup per CU;
         // eight waves give every SIMD a second wavefront to cover the s_waitcnt
         // stalls (LDS table reads of the normals, state/record traffic): +16 %
@@ -99,7 +99,7 @@ hipError_t launch_gauss_pt(int NT, const GaussArgs &m, const RwArgs &p, const Ch
 {
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
-        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false) + kIcdfDoubles);
+        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false) + icdf_doubles(c.nmode));
         constexpr int NW = (kNT >= 5) ? 8 : 4;
         return launch(k_run_rw<M, NW, false, false, true>, c.nblocks, NW, lds, st, m, p, c, r);
     })
@@ -110,7 +110,7 @@ hipError_t launch_gauss_pcn(int NT, const GaussArgs &m, const RwArgs &p, const C
 {
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
-        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false) + kIcdfDoubles);
+        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false) + icdf_doubles(c.nmode));
         if (r.pt_K > 0) return launch(k_run_rw<M, 4, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
         if (adapt) return launch(k_run_rw<M, 4, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
         return launch(k_run_rw<M, 4, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
@@ -122,7 +122,7 @@ hipError_t launch_gauss_hmc(int NT, const GaussArgs &m, const HmcArgs &p, const 
 {
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
-        const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
+        const size_t lds = sizeof(double) * (M::lds_doubles(true) + icdf_doubles(c.nmode));
         if (r.pt_K > 0) { // parallel tempering: HMC / MALA (with or without a mass matrix) within the rungs
             if (p.chM) return launch(k_run_hmc<M, 4, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
             return launch(k_run_hmc<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
@@ -141,7 +141,7 @@ hipError_t launch_propose_rw(int NT, const RwArgs &p, const ChainArgs &c, double
                              double *logq, hipStream_t st)
 {
     RMH_NT_DISPATCH(NT, {
-        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + kIcdfDoubles);
+        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + icdf_doubles(c.nmode));
         if (p.Vtiles) return launch(k_propose_rw<kNT, 4, true>, c.nblocks, 4, lds, st, p, c, theta_p, logq);
         return launch(k_propose_rw<kNT, 4, false>, c.nblocks, 4, lds, st, p, c, theta_p, logq);
     })
@@ -153,7 +153,7 @@ hipError_t launch_gauss_propose_hmc(int NT, const GaussArgs &m, const HmcArgs &p
 {
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
-        const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
+        const size_t lds = sizeof(double) * (M::lds_doubles(true) + icdf_doubles(c.nmode));
         if (p.chM) return launch(k_propose_hmc<M, 4, true>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
         return launch(k_propose_hmc<M, 4, false>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
     })
@@ -586,28 +586,37 @@ hipError_t launch_rng_seed(uint64_t *rng, int64_t ld, uint64_t seed, uint64_t ch
     return hipGetLastError();
 }
 
-// xi (T, ld, d) and u (T, ld) exactly as the fused kernels draw them
-__global__ void k_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const double *icdf,
+// xi (T, ld, d) and u (T, ld) exactly as the fused kernels draw them (nmode: the 64-bit normal mode)
+__global__ void k_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const double *icdf, int nmode,
                              double *xi, double *u)
 {
     extern __shared__ __attribute__((aligned(16))) double tab[];
-    icdf_stage(tab, icdf);
+    icdf_stage(tab, icdf, nmode);
     __syncthreads();
     const int lane = threadIdx.x & 63, cl = lane & 15, g = lane >> 4;
     const int64_t blk = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (blk >= ld / 16) return;
     const int64_t c = blk * 16 + cl, slot = blk * 64 + lane, nslots = 4 * ld;
     Xo x = xo_load(rng, nslots, slot);
-    const int Mw = (d + 7) / 8;
+    const int Mw = (d + 7) / 8, ks = (d + 3) / 4;
     for (int t = 0; t < T; ++t) {
-        for (int m = 0; m < Mw; ++m) {
-            const uint64_t w = xo_next(x);
-            const uint32_t hw[2] = {(uint32_t)(w >> 32), (uint32_t)w};
-            double zw[2];
-            normals_lockstep<2>(hw, tab, zw);
-            const double zh = zw[0], zl = zw[1];
-            if (8 * m + g < d) xi[((int64_t)t * ld + c) * d + 8 * m + g] = zh;
-            if (8 * m + 4 + g < d) xi[((int64_t)t * ld + c) * d + 8 * m + 4 + g] = zl;
+        if (nmode) {
+            for (int s = 0; s < ks; ++s) { // word s of sub-stream g is coordinate 4s + g
+                const uint64_t w[1] = {xo_next(x)};
+                double z[1];
+                normals64_lockstep<1>(w, tab, z);
+                if (4 * s + g < d) xi[((int64_t)t * ld + c) * d + 4 * s + g] = z[0];
+            }
+        } else {
+            for (int m = 0; m < Mw; ++m) {
+                const uint64_t w = xo_next(x);
+                const uint32_t hw[2] = {(uint32_t)(w >> 32), (uint32_t)w};
+                double zw[2];
+                normals_lockstep<2>(hw, tab, zw);
+                const double zh = zw[0], zl = zw[1];
+                if (8 * m + g < d) xi[((int64_t)t * ld + c) * d + 8 * m + g] = zh;
+                if (8 * m + 4 + g < d) xi[((int64_t)t * ld + c) * d + 8 * m + 4 + g] = zl;
+            }
         }
         if (u) { // null: the normals only
             const double uu = Tile<1>::accept_uniform(x, g, cl);
@@ -617,12 +626,12 @@ __global__ void k_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const doub
     xo_store(rng, nslots, slot, x);
 }
 
-hipError_t launch_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const double *icdf,
+hipError_t launch_rng_stream(uint64_t *rng, int64_t ld, int d, int T, const double *icdf, int nmode,
                              double *xi, double *u, hipStream_t st)
 {
     const int64_t nblocks = ld / 16;
     hipLaunchKernelGGL(k_rng_stream, dim3((unsigned)((nblocks + 3) / 4)), dim3(256),
-                       sizeof(double) * kIcdfDoubles, st, rng, ld, d, T, icdf, xi, u);
+                       sizeof(double) * icdf_doubles(nmode), st, rng, ld, d, T, icdf, nmode, xi, u);
     return hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ hipError_t launch_mix_hmc(int NT, const MixArgs &m, const HmcArgs &p, const Chai
 {
     RMH_NT_DISPATCH(NT, {
         using M = MixModel<kNT>;
-        const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
+        const size_t lds = sizeof(double) * (M::lds_doubles(true) + icdf_doubles(c.nmode));
         if (r.pt_K > 0) { // parallel tempering: HMC / MALA (with or without a mass matrix) within the rungs
             if (p.chM) return launch(k_run_hmc<M, 4, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
             return launch(k_run_hmc<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
@@ -41,7 +41,7 @@ hipError_t launch_mix_propose_hmc(int NT, const MixArgs &m, const HmcArgs &p, co
 {
     RMH_NT_DISPATCH(NT, {
         using M = MixModel<kNT>;
-        const size_t lds = sizeof(double) * (M::lds_doubles(true) + kIcdfDoubles);
+        const size_t lds = sizeof(double) * (M::lds_doubles(true) + icdf_doubles(c.nmode));
         if (p.chM) return launch(k_propose_hmc<M, 4, true>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
         return launch(k_propose_hmc<M, 4, false>, c.nblocks, 4, lds, st, m, p, c, theta_p, logq);
     })
@@ -52,7 +52,7 @@ hipError_t launch_mix_rw(int NT, const MixArgs &m, const RwArgs &p, const ChainA
 {
     RMH_NT_DISPATCH(NT, {
         using M = MixModel<kNT>;
-        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + kIcdfDoubles);
+        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + icdf_doubles(c.nmode));
         if (r.pt_K > 0)
             return launch(k_run_rw<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
         if (adapt)
@@ -66,7 +66,7 @@ hipError_t launch_mix_pcn(int NT, const MixArgs &m, const RwArgs &p, const Chain
 {
     RMH_NT_DISPATCH(NT, {
         using M = MixModel<kNT>;
-        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + kIcdfDoubles);
+        const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + icdf_doubles(c.nmode));
         if (r.pt_K > 0) return launch(k_run_rw<M, 4, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
         if (adapt) return launch(k_run_rw<M, 4, true, true, false>, c.nblocks, 4, lds, st, m, p, c, r);
         return launch(k_run_rw<M, 4, false, true, false>, c.nblocks, 4, lds, st, m, p, c, r);

@@ -272,6 +272,49 @@ struct Tile {
         }
     }
 
+    // The 64-bit-resolution normal mode (rmh_device.hpp): ks = ceil(d/4) words of the lane's sub-stream, word
+    // s is coordinate 4s + g (register s); zero beyond d.  Pairs in lockstep: a normal holds six
+    // 16-byte coefficient pairs.
+    static RMH_DEV void normals64(Xo &rng, int ks, int d, int g, const double *tab, double (&xi)[S])
+    {
+        if constexpr (S <= 8) { // the small tiles live on few registers and many waves per SIMD: one at a time
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                xi[s] = 0.0;
+                if (s < ks) {
+                    const uint64_t w[1] = {xo_next(rng)};
+                    double z[1];
+                    normals64_lockstep<1>(w, tab, z);
+                    xi[s] = (4 * s + g < d) ? z[0] : 0.0;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s0 = 0; s0 < S; s0 += 2) {
+                if (s0 < ks) {
+                    uint64_t w[2];
+                    double z[2];
+                    w[0] = xo_next(rng);
+                    w[1] = 0;
+                    if (s0 + 1 < ks) w[1] = xo_next(rng);
+                    normals64_lockstep<2>(w, tab, z);
+                    xi[s0] = (4 * s0 + g < d) ? z[0] : 0.0;
+                    xi[s0 + 1] = (s0 + 1 < ks && 4 * (s0 + 1) + g < d) ? z[1] : 0.0;
+                } else {
+                    xi[s0] = xi[s0 + 1] = 0.0;
+                }
+            }
+        }
+    }
+
+    // the kernel's normals in the chains' mode (nmode: ChainArgs::nmode, wave-uniform)
+    static RMH_DEV void normals_mode(int nmode, Xo &rng, int Mw, int ks, int d, int g, const double *tab,
+                                     double (&xi)[S])
+    {
+        if (nmode) normals64(rng, ks, d, g, tab, xi);
+        else normals(rng, Mw, d, g, tab, xi);
+    }
+
     // The same stream for a dimension known at compile time to need exactly MW words per
     // sub-stream and to be <= DMAX (8 (MW-1) < d <= min(8 MW, DMAX)): no wave-uniform word and
     // k-step predicates (in the generic version they live in spilled SGPRs: ~85 v_readlane and

@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
     if (!LGLOBAL)
         for (int i = threadIdx.x; i < tri_tiles(NT) * 64; i += blockDim.x) lds[i] = pr.Ltiles[i];
     M::setup(mlds, m, false);
-    icdf_stage(tab, ch.icdf);
+    icdf_stage(tab, ch.icdf, ch.nmode);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs p
         asm volatile("" ::: "memory");
         if (PT) pt.select(run, rng, cl);
         double xi[S];
-        T::normals(rng, ch.M, ch.d, g, tab, xi);
+        T::normals_mode(ch.nmode, rng, ch.M, ch.ks, ch.d, g, tab, xi);
         // theta' = theta + scale * L xi        (randomwalk.py:26; logqratio = 0.0)
         double4_t acc[NT];
         double thp[S], lpp, dummy[S], parts[2], logq = 0.0;
@@ -877,7 +877,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *tab = lds + M::lds_doubles(true);
     M::setup(lds, m, true);
-    icdf_stage(tab, ch.icdf);
+    icdf_stage(tab, ch.icdf, ch.nmode);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -949,7 +949,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
             // d = 16 NF + 1 .. 16 NF + 4 (the model's compile-time case): 2 NF + 1 words per sub-stream,
             // no wave-uniform word and k-step predicates (rmh_mfma.hpp)
             if constexpr (M::kTailNF > 0) T::template normals_fixed<2 * M::kTailNF + 1, 16 * M::kTailNF + 4>(rng, ch.d, g, tab, p);
-            else T::normals(rng, ch.M, ch.d, g, tab, p);
+            else T::normals_mode(ch.nmode, rng, ch.M, ch.ks, ch.d, g, tab, p);
         }
         T::load_state(ch.theta, ch.ld, c, g, q);
         if (LPMEM) lp = buf_load(rs_lp(), vo_lp, 0u);
@@ -1119,7 +1119,7 @@ __global__ void __launch_bounds__(64 * NW) k_propose_rw(RwArgs pr, ChainArgs ch,
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *tab = lds + tri_tiles(NT) * 64;
     for (int i = threadIdx.x; i < tri_tiles(NT) * 64; i += blockDim.x) lds[i] = pr.Ltiles[i];
-    icdf_stage(tab, ch.icdf);
+    icdf_stage(tab, ch.icdf, ch.nmode);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cl = lane & 15, g = lane >> 4;
@@ -1129,7 +1129,7 @@ __global__ void __launch_bounds__(64 * NW) k_propose_rw(RwArgs pr, ChainArgs ch,
     double th[S], xi[S];
     T::load_state(ch.theta, ch.ld, c, g, th);
     Xo rng = xo_load(ch.rng, ch.nslots, slot);
-    T::normals(rng, ch.M, ch.d, g, tab, xi);
+    T::normals_mode(ch.nmode, rng, ch.M, ch.ks, ch.d, g, tab, xi);
     double4_t acc[NT];
     if (PCN) {
         double thp[S], ufw[S], urv[S];
@@ -1174,7 +1174,7 @@ __global__ void __launch_bounds__(64 * NW) k_propose_hmc(typename M::Args m, Hmc
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *tab = lds + M::lds_doubles(true);
     M::setup(lds, m, true);
-    icdf_stage(tab, ch.icdf);
+    icdf_stage(tab, ch.icdf, ch.nmode);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cl = lane & 15, g = lane >> 4;
@@ -1185,7 +1185,7 @@ __global__ void __launch_bounds__(64 * NW) k_propose_hmc(typename M::Args m, Hmc
     double q[S], p[S], gr[S], lpp, parts[2];
     T::load_state(ch.theta, ch.ld, c, g, q);
     Xo rng = xo_load(ch.rng, ch.nslots, slot);
-    T::normals(rng, ch.M, ch.d, g, tab, p);
+    T::normals_mode(ch.nmode, rng, ch.M, ch.ks, ch.d, g, tab, p);
     double k0 = 0.0;
 #pragma unroll
     for (int s = 0; s < S; ++s) k0 += p[s] * p[s];

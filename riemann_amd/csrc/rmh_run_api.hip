@@ -195,13 +195,16 @@ static int acov_update(rmh_proposal *p)
     return sync_proposal(p);
 }
 
+// the VALU-tail kernels draw a compile-time number of 32-bit-resolution normals: not in the 64-bit normal mode
+static bool tail_ok(const ChainArgs &c) { return !c.nmode && !policy(RMH_POLICY_NO_TAIL); }
+
 // adapt: the AdaptScale variant (per-chain scale in c.adapt, unscaled tile image)
 static hipError_t launch_rw_plain(rmh_model *m, rmh_proposal *p, const ChainArgs &c, const RunArgs &r, bool adapt)
 {
     RwArgs ra{p->d_Ltiles, nullptr, 0.0};
     switch (m->kind) {
     case kGauss:
-        if (m->ga.Wtail && p->d_Ltail && !policy(RMH_POLICY_NO_TAIL)) { // d = 97..100: rmh_run.hpp, k_run_rw_tail
+        if (m->ga.Wtail && p->d_Ltail && tail_ok(c)) { // d = 97..100: rmh_run.hpp, k_run_rw_tail
             ra.Ltail = p->d_Ltail;
             return launch_gauss_rw_tail(m->ga, ra, c, r, adapt, g_stream);
         }
@@ -233,7 +236,7 @@ static int run_adaptcov(rmh_model *m, rmh_proposal *p, rmh_state *s, const Chain
     int rc;
     const int64_t rows = 4 * s->ks, ld = s->ld;
     const bool fused = p->kind == kRW && m->kind == kGauss && m->ga.Wtail && p->d_Ltail && !c.adapt &&
-                       p->acov_NT == 7 && !policy(RMH_POLICY_NO_TAIL) && !policy(RMH_POLICY_ACOV_UNFUSED);
+                       p->acov_NT == 7 && tail_ok(c) && !policy(RMH_POLICY_ACOV_UNFUSED);
     int mom_passes = 1;
     const int64_t nwg = fused ? gauss_rw_tail_mom_grid(c.nblocks, &mom_passes) : kAcovWGs;
     const size_t need = (size_t)nwg * acov_ntri(p) * 256;
@@ -416,6 +419,7 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
         if (p->kind != kCpRJ || m->kind != kChangepointRJ || adapt || K > 0)
             return fail(RMH_ERR_PARAM, "run: the variable-k changepoint model goes with "
                                        "ChangepointRegression1DProp (and nothing else)");
+        if (c.nmode) return fail(RMH_ERR_PARAM, "run: normals=\"f64\" is not built for the variable-k changepoint kernels");
         CpRjArgs ra = m->rj;
         ra.sv = std::sqrt(0.01 * p->hscale * p->hscale / ra.base.n);   // test_changepoint.py:37
         ra.ss = std::sqrt(0.01 * p->hscale);                            // :38
@@ -424,6 +428,7 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
     } else if (m->big) { // 112 < d <= 896
         if (p->kind != kRW || adapt || K > 0 || p->acov || p->nblk > 0)
             return fail(RMH_ERR_PARAM, "run: for d > 112 only the plain random walk on the Gaussian model is built");
+        if (c.nmode) return fail(RMH_ERR_PARAM, "run: normals=\"f64\" is not built for d > 112");
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
         e = launch_big_gauss_rw(m->NT, m->ga, ra, c, r, g_stream);
     } else if (p->acov) {
@@ -447,7 +452,7 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
                                       : launch_mix_pcn(m->NT, m->ma, ra, c, r, false, g_stream);
     } else if (K > 0) {
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
-        const bool tail = m->kind == kGauss && m->ga.Wtail && p->d_Ltail && !policy(RMH_POLICY_NO_TAIL);
+        const bool tail = m->kind == kGauss && m->ga.Wtail && p->d_Ltail && tail_ok(c);
         if (tail) ra.Ltail = p->d_Ltail;
         e = tail                      ? launch_gauss_rw_tail(m->ga, ra, c, r, false, g_stream)
             : m->kind == kGauss       ? launch_gauss_pt(m->NT, m->ga, ra, c, r, g_stream)
@@ -466,17 +471,19 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
             if (m->kind != kChangepoint || adapt)
                 return fail(RMH_ERR_PARAM, "run: block-mixture proposals are built for the changepoint model, "
                                            "without scale adaptation");
+            if (c.nmode) return fail(RMH_ERR_PARAM, "run: normals=\"f64\" is not built for the block-mixture proposal");
             ra.nblk = p->nblk;
             for (int b = 0; b < 3; ++b) {
                 ra.blk_end[b] = p->blk_end[b];
                 ra.blk_p[b] = p->blk_p[b];
             }
         }
-        if (m->kind == kGauss && m->ga.Wtail && p->d_Ltail && !policy(RMH_POLICY_NO_TAIL)) {
+        if (m->kind == kGauss && m->ga.Wtail && p->d_Ltail && tail_ok(c)) {
             ra.Ltail = p->d_Ltail;   // d = 97..100: rows 96..99 on the VALU instead of a 7th row tile
             e = launch_gauss_rw_tail(m->ga, ra, c, r, adapt, g_stream);
         } else if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
-        else if (m->kind == kChangepoint && adapt) e = launch_cp_generic(m->k, m->ca, ra, c, r, 1, g_stream);
+        else if (m->kind == kChangepoint && (adapt || c.nmode)) // (64-bit normals: the generic kernel over the changepoint policy)
+            e = launch_cp_generic(m->k, m->ca, ra, c, r, adapt ? 1 : 0, g_stream);
         else if (m->kind == kChangepoint && p->L_is_diag && m->ca.ss_xp && m->ca.alpha_m1 == 0.0 &&
                  !policy(RMH_POLICY_CP_NO_SS)) {
             // BASELINE cfg 5 (and the block-mixture proposal at fixed k): diagonal proposal factor,

@@ -82,7 +82,7 @@ class _Rung(object):
 class PTSampler(object):
     """A parallel-tempered Sampler (ptsampler.py:42-127) for Ne ensembles at once."""
 
-    def __init__(self, model, proposal, theta0, betas=None, Pswap=0.1, seed=0, chain0=0):
+    def __init__(self, model, proposal, theta0, betas=None, Pswap=0.1, seed=0, chain0=0, normals="f32x2"):
         """
         :param model: device Model to sample (MultiGaussianDist or MixtureDist)
         :param proposal: the proposal used within every rung (MetropolisRandomWalk, pCN,
@@ -93,6 +93,7 @@ class PTSampler(object):
         :param Pswap: probability of proposing a swap instead of a within-chain step
         :param seed, chain0: rmh-rng stream; ``chain0`` = global id of the first SLOT
             (a multiple of 16 when the ensembles of a job are split over GPUs)
+        :param normals: resolution of the stream's normals, as ``Sampler``
         """
         if not isinstance(model, DeviceModel) or not isinstance(proposal, DeviceProposal):
             raise TypeError("riemann_amd.PTSampler runs on the GPU: model and proposal must be "
@@ -124,6 +125,9 @@ class PTSampler(object):
         slots[self._idx] = th[:, None, :]
         self._state = C.c_void_p()
         _lib.call("rmh_state_create", model._h, self._S, int(seed), int(chain0), C.byref(self._state))
+        self.normals = normals
+        if _lib.normal_mode(normals):
+            _lib.call("rmh_state_set_normal_mode", self._state, _lib.normal_mode(normals))
         _lib.call("rmh_state_set_theta", self._state, slots)
         self._hist = None
         # T = 0 run: evaluates the tempered posteriors of the starting states

@@ -31,7 +31,7 @@ from ..proposals.proposal import DeviceProposal
 class Sampler(object):
     """Given a Model and a Proposal, sample the Model using the Proposal."""
 
-    def __init__(self, model, proposal, theta0, seed=0, chain0=0):
+    def __init__(self, model, proposal, theta0, seed=0, chain0=0, normals="f32x2"):
         """
         :param model: a device Model (riemann_amd.models)
         :param proposal: a device Proposal (riemann_amd.proposals)
@@ -39,16 +39,26 @@ class Sampler(object):
         :param seed: seed of the rmh-rng stream
         :param chain0: global id of the first chain (chains of a multi-GPU job
             keep their streams whatever the number of GPUs)
+        :param normals: ``"f32x2"`` (default): two standard normals per 64-bit stream word, each the
+            quantile of a 32-bit half word (|z| <= 6.4, a lattice of 2^-27 in p); ``"f64"``: one
+            normal per word at float64 resolution (52 bits inside a cell, |z| <= 8.6, the map good
+            to 2e-16) -- what ``np.random.normal`` gives the reference (randomwalk.py:25) -- on
+            the generic kernels (fused device path; not d > 112, the block-mixture and the
+            variable-k changepoint proposals)
         """
         if not hasattr(model, "log_posterior") or not hasattr(proposal, "propose"):
             raise TypeError("Sampler needs a Model (log_posterior) and a Proposal (propose)")
         self.model = model
         self.proposal = proposal
         self._seed, self._chain0 = int(seed), int(chain0)
+        self.normals, nmode = normals, _lib.normal_mode(normals)
         self._state = self._hist = None
         self.pin_history, self._pool = True, None
         self.last_run_ms = None
         if not self._fused():
+            if nmode:
+                raise _lib.ParameterError("normals=\"f64\" is built for the fused device path (device Model + "
+                                          "device Proposal), not for Python plugins")
             self._init_mixed(theta0)
             return
         th = model._pack_theta(theta0)
@@ -62,6 +72,8 @@ class Sampler(object):
         self._state = C.c_void_p()
         _lib.call("rmh_state_create", model._h, self.Nchains, int(seed), int(chain0),
                   C.byref(self._state))
+        if nmode:
+            _lib.call("rmh_state_set_normal_mode", self._state, nmode)
         _lib.call("rmh_state_set_theta", self._state, th)   # sampler.py:42
         lp = np.empty(self.Nchains)
         _lib.call("rmh_state_get", self._state, None, lp.ctypes.data)
@@ -498,7 +510,8 @@ class Sampler(object):
         extra["adapt_aux"] = aux
         if hasattr(self.proposal, "_adapt_cov_state"):      # AdaptCov*: the pooled accumulators
             extra["adapt_cov"] = self.proposal._adapt_cov_state()
-        np.savez(path, theta=th, logpost=lp, rng=rng, adapt=ad, single=np.bool_(self._single), **extra)
+        np.savez(path, theta=th, logpost=lp, rng=rng, adapt=ad, single=np.bool_(self._single),
+                 normals=np.str_(self.normals), **extra)
 
     def restore(self, path):
         """Load a checkpoint written by :meth:`checkpoint` into this Sampler (same
@@ -508,6 +521,10 @@ class Sampler(object):
         if z["theta"].shape != (self.Nchains, self.Npars):
             raise _lib.ParameterError("checkpoint holds states of shape {}, sampler has {}"
                                       .format(z["theta"].shape, (self.Nchains, self.Npars)))
+        saved = str(z["normals"]) if "normals" in z.files else "f32x2"
+        if saved != self.normals:
+            raise _lib.ParameterError("checkpoint was written with normals={!r}, this sampler draws {!r}: the "
+                                      "chains would not continue their stream".format(saved, self.normals))
         self._arch = []
         if self._state is None:
             self._th, self._lp = _lib.as_f64(z["theta"]).copy(), _lib.as_f64(z["logpost"]).copy()

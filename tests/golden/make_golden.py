@@ -127,6 +127,27 @@ def g0_rng():
     save("g0_rng", seed=np.uint64(12345), chain0=np.uint64(7), **arrs)
 
 
+def g18_f64_normals():
+    """The 64-bit-resolution normal mode (Sampler(..., normals="f64")): the stream itself (as G0) and the
+    reference's Sampler on it -- cfg2's shape and a 100-d HMC trajectory -- with every normal drawn from
+    one whole stream word."""
+    with orc.normal_mode("f64"):
+        arrs = {}
+        for d in (1, 2, 5, 12, 100):
+            st = orc.rng_seed(12345, 3, chain0=7)
+            xi, u = orc.rng_stream(st, d, 3)
+            arrs["xi_d%d" % d], arrs["u_d%d" % d], arrs["state3_d%d" % d] = xi, u, st.copy()
+        save("g18_rng_f64", seed=np.uint64(12345), chain0=np.uint64(7), **arrs)
+        Ct = corr100()
+        Cp = (2.38 ** 2 / 100.0) * Ct
+        th0 = np.random.default_rng(1).standard_normal((6, 100)) @ np.linalg.cholesky(Ct).T
+        r = run_reference(rbench.benchmark_gauss100d_corr, lambda: MetropolisRandomWalk(Cp), th0, seed=18, T=32)
+        save("g18_gauss100d_rw_f64", mu=np.zeros(100), prop_factor=np.float64(2.38 ** 2 / 100.0), **r)
+        m = rbench.benchmark_gauss100d_corr
+        r = run_reference(m, lambda: VanillaHMC(0.28, 5, m.grad_log_likelihood), th0[:3], seed=19, T=12)
+        save("g18_gauss100d_hmc5_f64", eps=np.float64(0.28), nsteps=np.int64(5), **r)
+
+
 # ----------------------------------------------- G1/G2: random-walk Gaussian --
 def g1_gauss2d_rw():
     """cfg1: benchmark_gauss2d_iso (models/benchmarks.py:15) + MetropolisRandomWalk(I2)."""
@@ -927,3 +948,4 @@ if __name__ == "__main__":
     g15_gauss_big_d()
     g16_reference_example()
     g17_changepoint_rj()
+    g18_f64_normals()

@@ -112,9 +112,49 @@ def normal_from_half(h):
     return -z if (h & 1) else z
 
 
-def stream_normals_uniform(seed, chain, d, T):
+_TABLE64 = None
+
+
+def table64():
+    global _TABLE64
+    if _TABLE64 is None:
+        import os
+        _TABLE64 = np.load(os.path.join(os.path.dirname(__file__), "golden", "icdf64_table.npy"))
+    return _TABLE64
+
+
+def normal_from_word(x):
+    """the 64-bit-resolution normal mode: one standard normal per stream word
+    (tools/gen_icdf_table.py --f64; all 56 rows, degree 10 in t)."""
+    tab = table64()
+    q = x | 1
+    r = min(64 - q.bit_length(), 55)
+    N = ((q << r) & M64) | (1 << 63)
+    j = (N >> 60) & 7
+    mant = (N >> 8) & ((1 << 52) - 1)
+    v = float(Fraction(1) + Fraction(mant, 1 << 52))      # exact
+    t = fma(2.0, v, -3.0)
+    c = tab[r, j]
+    z = float(c[-1])
+    for k in range(len(c) - 2, -1, -1):
+        z = fma(z, t, float(c[k]))
+    return -z if (x & 1) else z
+
+
+def stream_normals_uniform(seed, chain, d, T, mode="f32x2"):
     """xi (T,d), u (T,) of GLOBAL chain id `chain`."""
     st = [stream_init(seed, 4 * chain + g) for g in range(4)]
+    if mode == "f64":                 # word s of sub-stream g is coordinate 4s+g, ceil(d/4) words each
+        xi = np.zeros((T, d))
+        u = np.zeros(T)
+        for t in range(T):
+            for g in range(4):
+                for s in range((d + 3) // 4):
+                    z = normal_from_word(nxt(st[g]))
+                    if 4 * s + g < d:
+                        xi[t, 4 * s + g] = z
+            u[t] = float(nxt(st[0]) >> 11) * 2.0 ** -53
+        return xi, u
     M = (d + 7) // 8
     xi = np.zeros((T, d))
     u = np.zeros(T)

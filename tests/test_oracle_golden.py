@@ -196,6 +196,80 @@ def test_rng_matches_pure_python_restatement():
             np.testing.assert_array_equal(u[:, c], eu)
 
 
+# ---- the 64-bit-resolution normal mode (Sampler(..., normals="f64")) -------------------------
+def _p_of_word(w):
+    """tail probability and sign a stream word encodes in the 64-bit normal mode (rmh_oracle.c section 1)"""
+    q = w | 1
+    r = min(64 - q.bit_length(), 55)
+    N = ((q << r) & (2 ** 64 - 1)) | 2 ** 63
+    j, mant = (N >> 60) & 7, (N >> 8) & (2 ** 52 - 1)
+    return 2.0 ** (-2 - r) * (1 + (j + mant * 2.0 ** -52) / 8), w & 1
+
+
+def test_f64_mode_normals_are_accurate_out_to_the_tails():
+    """z(word) against scipy's normal quantile at the tail probability the word encodes: random words,
+    every row of the table (leading zeros 0..63 -> p down to 2^-58, 8.5 sigma), cell edges."""
+    from scipy.stats import norm
+    g = np.random.default_rng(2)
+    words = [int(w) for w in g.integers(0, 2 ** 64, 3000, dtype=np.uint64)]
+    for r in range(64):                                  # a word with r leading zeros, random below
+        words += [(1 << (63 - r)) | int(g.integers(0, 1 << (63 - r))) if r < 63 else 1 for _ in range(8)]
+    words += [0, 1, 2, 3, 2 ** 64 - 1, 2 ** 63, 2 ** 63 + 1, 2 ** 60 - 1, 2 ** 60, (2 ** 61 - 1) << 3]
+    zmax = 0.0
+    for w in words:
+        z = orc.normal_from_word(w)
+        p, sign = _p_of_word(w)
+        ref = norm.isf(p)
+        assert abs(abs(z) - ref) <= 2e-15 * max(1.0, ref), (hex(w), z, ref)
+        assert (z < 0) == bool(sign) or z == 0
+        zmax = max(zmax, abs(z))
+    assert orc.normal_from_word(0xABCDEF12345678 * 2) == -orc.normal_from_word(0xABCDEF12345678 * 2 + 1)
+    assert 8.5 < zmax < 8.6 and abs(orc.normal_from_word(0)) == zmax      # p = 2^-57
+    # finer than the default stream (which reads 32 bits): words that differ in bit 20 only give different normals
+    assert orc.normal_from_word(0x4000000000100000) != orc.normal_from_word(0x4000000000000000)
+
+
+def test_f64_mode_stream_matches_pure_python_restatement_and_fixture():
+    from tests.rng_spec import stream_normals_uniform
+    with orc.normal_mode("f64"):
+        for d in (1, 5, 12):
+            st = orc.rng_seed(99, 2, chain0=3)
+            xi, u = orc.rng_stream(st, d, 2)
+            for c in range(2):
+                exi, eu = stream_normals_uniform(99, 3 + c, d, 2, mode="f64")
+                np.testing.assert_array_equal(xi[:, c], exi)
+                np.testing.assert_array_equal(u[:, c], eu)
+        z = load("g18_rng_f64")
+        for d in (1, 2, 5, 12, 100):
+            st = orc.rng_seed(int(z["seed"]), 3, chain0=int(z["chain0"]))
+            xi, u = orc.rng_stream(st, d, 3)
+            np.testing.assert_array_equal(xi, z["xi_d%d" % d])
+            np.testing.assert_array_equal(u, z["u_d%d" % d])
+            np.testing.assert_array_equal(st, z["state3_d%d" % d])
+        xi, u = orc.rng_stream(orc.rng_seed(7, 2048), 100, 4)
+    assert orc.lib().orc_get_normal_mode() == 0           # the context manager restores the default
+    assert abs(xi.mean()) < 4 / np.sqrt(xi.size) and abs(xi.var() - 1) < 0.01 and abs(np.mean(xi ** 4) - 3) < 0.06
+    c = np.corrcoef(xi.reshape(-1, 100), rowvar=False)
+    assert np.abs(c - np.eye(100)).max() < 0.08
+
+
+def test_g18_reference_runs_on_the_f64_stream():
+    """the oracle on the 64-bit-mode stream against the reference's Sampler on the same stream"""
+    Ct = corr100()
+    with orc.normal_mode("f64"):
+        z = load("g18_gauss100d_rw_f64")
+        m = orc.Gaussian(np.zeros(100), Ct)
+        th = z["theta0"].copy()
+        ht, hl, acc = orc.run(m, orc.RandomWalk(float(z["prop_factor"]) * Ct), th, m.log_posterior(th),
+                              orc.rng_seed(int(z["seed"]), th.shape[0]), 32)
+        check_run(z, ht, hl, acc)
+        z = load("g18_gauss100d_hmc5_f64")
+        th = z["theta0"].copy()
+        ht, hl, acc = orc.run(m, orc.HMC(float(z["eps"]), int(z["nsteps"]), 100), th, m.log_posterior(th),
+                              orc.rng_seed(int(z["seed"]), th.shape[0]), 12)
+        check_run(z, ht, hl, acc)
+
+
 def test_normals_are_standard_normal():
     xi, u = orc.rng_stream(orc.rng_seed(7, 4096), 100, 4)
     assert abs(xi.mean()) < 4 / np.sqrt(xi.size)

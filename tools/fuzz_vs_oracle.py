@@ -5,7 +5,9 @@ the device against the CPU oracle.  Test infrastructure (uses oracle/).   python
 Every configuration runs under a random kernel policy (riemann_amd._lib.kernel_policy: half of them the
 library's own choice, the others a random subset of the A/B switches), so that the specialised kernels --
 one-lane-per-chain changepoint kernels at small chain counts, the VALU tail rows against the padded tiles,
-the in-kernel moments of the covariance adaptation against the scratch history -- all meet the oracle."""
+the in-kernel moments of the covariance adaptation against the scratch history -- all meet the oracle.
+A third of the configurations that can (not d > 112, block-mixture or variable-k proposals) draw their normals
+in the 64-bit-resolution mode, Sampler(..., normals="f64"), against the oracle in the same mode."""
 import os
 import sys
 import traceback
@@ -71,7 +73,7 @@ def one_cprj(g):
     return desc + " cprj"
 
 
-def one(g, it):
+def one(g, it, want64=False):
     kind = g.choice(["gauss", "gauss", "logreg", "mix", "cp", "bigd", "cprj"])
     if kind == "cprj":
         return one_cprj(g)
@@ -133,7 +135,9 @@ def one(g, it):
     if kind == "bigd":
         props = ["rw"]
     pk = str(g.choice(props))
-    desc = "%s d=%d N=%d T=%d nb=%d nt=%d %s" % (kind, d, N, T, nb, nt, pk)
+    nm = "f64" if (want64 and kind != "bigd" and pk != "block") else "f32x2"
+    orc.lib().orc_set_normal_mode(1 if nm == "f64" else 0)     # (main() resets it after the configuration)
+    desc = "%s d=%d N=%d T=%d nb=%d nt=%d %s%s" % (kind, d, N, T, nb, nt, pk, " f64" if nm == "f64" else "")
     seed = int(g.integers(0, 2 ** 31))
     ad = aux = None
     th, st = th0.copy(), orc.rng_seed(seed, N)
@@ -156,7 +160,7 @@ def one(g, it):
             desc += " pcn"
         else:
             wprop, oprop = P.MetropolisRandomWalk(Cp), orc.RandomWalk(Cp)
-        pt = PTSampler(m, wprop, th0, betas=betas, Pswap=pswap, seed=seed, chain0=chain0)
+        pt = PTSampler(m, wprop, th0, betas=betas, Pswap=pswap, seed=seed, chain0=chain0, normals=nm)
         T1 = int(g.integers(0, T + 1))
         pt.run(T1)                       # histories append across run() calls
         pt.run(T - T1)
@@ -210,7 +214,7 @@ def one(g, it):
         else:
             Cp = spd(g, d)
             p, op = P.AdaptCovHMC(0.2, 2, m, Cp, t_adapt=50, smooth_adapt=True, exact_squares=sq), orc.HMC(0.2, 2, d, M=Cp)
-        s = ra.Sampler(m, p, th0, seed=seed)
+        s = ra.Sampler(m, p, th0, seed=seed, normals=nm)
         s.run(T, nb, nt)
         stc = orc.new_adaptcov_state(Cp)
         ht, hl, acc = orc.run_adaptcov(om, op, th, om.log_posterior(th), st, T, stc, Cp,
@@ -218,7 +222,7 @@ def one(g, it):
         assert np.array_equal(s._chain_accept, acc), desc + " accept"
         np.testing.assert_allclose(s._chain_thetas, ht[nb::nt], rtol=1e-7, atol=1e-10, err_msg=desc)
         return desc
-    s = ra.Sampler(m, p, th0, seed=seed)
+    s = ra.Sampler(m, p, th0, seed=seed, normals=nm)
     s.run(T, nb, nt)
     lp0 = om.log_posterior(th)
     ht, hl, acc = orc.run(om, op, th, lp0, st, T, adapt=ad, aux=aux)
@@ -265,14 +269,17 @@ def main():
     bad = 0
     for it in range(n):
         pol = random_policy(gp)
+        want64 = gp.uniform() < 0.34
         try:
             with kernel_policy(*pol):
-                d = one(g, it)
+                d = one(g, it, want64)
             print("ok  ", d, ("[" + ",".join(pol) + "]") if pol else "", flush=True)
         except Exception as e:           # keep going: collect every failing configuration
             bad += 1
             print("FAIL", "[" + ",".join(pol) + "]", repr(e)[:300], flush=True)
             traceback.print_exc(limit=2)
+        finally:
+            orc.lib().orc_set_normal_mode(0)
     print("%d configurations, %d failed" % (n, bad))
     sys.exit(1 if bad else 0)
 

@@ -162,6 +162,9 @@ int rmh_proposal_free(rmh_proposal_t p);
  * theta_p (N,d), logqratio (N).  rng (N,16) uint64 is advanced in place. */
 int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
                 uint64_t *rng, double *theta_p, double *logq);
+/* the same with the normals of a given mode (rmh_state_set_normal_mode; 0 = rmh_propose) */
+int rmh_propose_mode(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
+                     uint64_t *rng, int normal_mode, double *theta_p, double *logq);
 /* The draws of T iterations of Sampler.sample for N chains from the host copy of their stream
  * state ((N,16) uint64, advanced in place): per iteration the d standard normals of
  * proposals/randomwalk.py:25 / proposals/hamiltonian.py:79 (xi, (T,N,d); d = 0: none, xi may be

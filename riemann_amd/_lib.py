@@ -66,6 +66,7 @@ SIGNATURES = {
     "rmh_proposal_set_adapt": [_vp, _dbl],
     "rmh_proposal_free": [_vp],
     "rmh_propose": [_vp, _vp, _f64, _i64, _u64, _f64, _f64],
+    "rmh_propose_mode": [_vp, _vp, _f64, _i64, _u64, _int, _f64, _f64],
     "rmh_rng_draw": [_u64, _i64, _int, _int, _vp, _vp],
     "rmh_rng_draw_mode": [_u64, _i64, _int, _int, _int, _vp, _vp],
     "rmh_state_set_normal_mode": [_vp, _int],

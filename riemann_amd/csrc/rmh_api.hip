@@ -977,8 +977,15 @@ int rmh_proposal_free(rmh_proposal_t p)
 int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N, uint64_t *rng,
                 double *theta_p, double *logq)
 {
+    return rmh_propose_mode(m, p, theta, N, rng, 0, theta_p, logq);
+}
+
+int rmh_propose_mode(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N, uint64_t *rng, int normal_mode,
+                     double *theta_p, double *logq)
+{
     RMH_NEED_INIT();
-    if (!p || !theta || !rng || !theta_p || !logq || N < 1) return fail(RMH_ERR_PARAM, "bad argument");
+    if (!p || !theta || !rng || !theta_p || !logq || N < 1 || (normal_mode != 0 && normal_mode != 1))
+        return fail(RMH_ERR_PARAM, "bad argument");
     if (p->kind == kCpRJ) return fail(RMH_ERR_PARAM, "propose: stand-alone trans-dimensional proposals are not built");
     if (p->kind == kHMC && !m) return fail(RMH_ERR_PARAM, "hmc: needs a device Model for the gradient");
     if (m && m->d != p->d)
@@ -991,6 +998,7 @@ int rmh_propose(rmh_model_t m, rmh_proposal_t p, const double *theta, int64_t N,
     int rc = tmp_state(t, m ? m : &shape, theta, N);
     if (rc) return rc;
     rmh_state &s = t.s;
+    s.nmode = normal_mode;
     std::vector<uint64_t> dev;
     rng_to_device_layout(rng, N, s.ld, dev);
     if ((rc = upload(&s.rng, dev.data(), dev.size()))) return rc;

@@ -84,7 +84,8 @@ class VanillaHMC(DeviceProposal):
         if d != self.Npars:
             raise _lib.ParameterError("theta and M have incompatible shapes")
         p = np.empty((1, N, d))
-        _lib.call("rmh_rng_draw", self._stream(N) if rng is None else rng, N, d, 1, p.ctypes.data, None)
+        _lib.call("rmh_rng_draw_mode", self._stream(N) if rng is None else rng, N, d, 1,
+                  _lib.normal_mode(self.normals), p.ctypes.data, None)
         p = p[0]                                                   # p ~ N(0, I), hamiltonian.py:79
         k0 = np.sum(p * p, axis=1)
         # AdaptScaleHMC on a Python gradient: eps = scale * eps0 per chain (hamiltonian.py:101-102); the Sampler

@@ -43,8 +43,8 @@ class Sampler(object):
             quantile of a 32-bit half word (|z| <= 6.4, a lattice of 2^-27 in p); ``"f64"``: one
             normal per word at float64 resolution (52 bits inside a cell, |z| <= 8.6, the map good
             to 2e-16) -- what ``np.random.normal`` gives the reference (randomwalk.py:25) -- on
-            the generic kernels (fused device path; not d > 112, the block-mixture and the
-            variable-k changepoint proposals)
+            the generic kernels (not d > 112, the block-mixture and the variable-k changepoint
+            proposals) and for a device Proposal next to a Python Model
         """
         if not hasattr(model, "log_posterior") or not hasattr(proposal, "propose"):
             raise TypeError("Sampler needs a Model (log_posterior) and a Proposal (propose)")
@@ -56,9 +56,13 @@ class Sampler(object):
         self.pin_history, self._pool = True, None
         self.last_run_ms = None
         if not self._fused():
-            if nmode:
-                raise _lib.ParameterError("normals=\"f64\" is built for the fused device path (device Model + "
-                                          "device Proposal), not for Python plugins")
+            # mixed plugins: a device Proposal (or the momenta of a host-gradient HMC) draws the chains' normals
+            # through rmh_propose_mode / rmh_rng_draw_mode in this Sampler's mode
+            if nmode and not isinstance(proposal, DeviceProposal):
+                raise _lib.ParameterError("normals=\"f64\" concerns the device stream's normals: this proposal is a "
+                                          "Python plugin and draws its own")
+            if isinstance(proposal, DeviceProposal):
+                proposal.normals = normals
             self._init_mixed(theta0)
             return
         th = model._pack_theta(theta0)

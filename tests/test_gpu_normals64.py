@@ -194,11 +194,32 @@ def test_f64_mode_refusals_and_checkpoints(ra, tmp_path):
     with pytest.raises(ParameterError, match="variable-k"):
         ra.Sampler(rj, ChangepointRegression1DProp(rj, float(z["hscale"])), z["theta0"], normals="f64")
 
-    class HostModel(object):                     # a Python plugin: the mixed path has no 64-bit mode
+    class HostModel(object):                     # a Python plugin next to the device proposal: the mixed path
         def log_posterior(self, th):
             return -0.5 * float(np.sum(th * th))
-    with pytest.raises(ParameterError, match="fused device path"):
-        ra.Sampler(HostModel(), MetropolisRandomWalk(np.eye(4)), np.zeros(4), normals="f64")
+
+    class HostProposal(object):
+        def propose(self, th):
+            return th, 0.0
+    with pytest.raises(ParameterError, match="draws its own"):
+        ra.Sampler(HostModel(), HostProposal(), np.zeros(4), normals="f64")
+    # mixed plugins in the 64-bit mode == the fused device run of the same target; stand-alone propose() likewise
+    th0 = np.random.default_rng(3).standard_normal((20, 4))
+    mixed = ra.Sampler(HostModel(), MetropolisRandomWalk(0.5 * np.eye(4)), th0, seed=6, normals="f64")
+    mixed.run(15)
+    fused = ra.Sampler(m, MetropolisRandomWalk(0.5 * np.eye(4)), th0, seed=6, normals="f64")
+    fused.run(15)
+    np.testing.assert_array_equal(mixed._chain_accept, fused._chain_accept)
+    np.testing.assert_allclose(mixed._chain_thetas, fused._chain_thetas, rtol=1e-12, atol=1e-14)
+    fused32 = ra.Sampler(m, MetropolisRandomWalk(0.5 * np.eye(4)), th0, seed=6)
+    fused32.run(15)
+    assert not np.array_equal(fused32._chain_thetas, fused._chain_thetas)
+    pr = MetropolisRandomWalk(0.5 * np.eye(4))
+    pr.normals = "f64"
+    pr.seed(6)
+    thp, lq = pr.propose(th0)
+    np.testing.assert_allclose(thp[fused._chain_accept[0] == 1], fused._chain_thetas[1][fused._chain_accept[0] == 1],
+                               rtol=1e-12, atol=1e-14)
     # a checkpoint remembers its mode; resuming continues the same chains
     th0 = np.random.default_rng(0).standard_normal((40, 4))
     a = ra.Sampler(m, MetropolisRandomWalk(np.eye(4)), th0, seed=2, normals="f64")

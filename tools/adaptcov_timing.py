@@ -3,7 +3,10 @@
 plain random walk vs AdaptCovRandomWalk with the reference's float update test and with
 updates at perfect squares only.  Prints ms per T (default 1000) iterations and launches.
 
-    python tools/adaptcov_timing.py [T] [float|squares|plain ...]"""
+    python tools/adaptcov_timing.py [T] [float|squares|plain|hmc|scalecov ...]
+
+The HMC variant (AdaptCovHMC: the adapted covariance becomes the mass matrix) and the walk with both scale and
+covariance adaptation (AdaptScaleCovRandomWalk) take the scratch-history route; their plain counterparts beside them."""
 import ctypes as C
 import os
 import sys
@@ -15,7 +18,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import riemann_amd as ra                                                    # noqa: E402
 from riemann_amd import _lib, workloads as W                                 # noqa: E402
 from riemann_amd.models import MultiGaussianDist                            # noqa: E402
-from riemann_amd.proposals import AdaptCovRandomWalk, MetropolisRandomWalk   # noqa: E402
+from riemann_amd.proposals import (AdaptCovHMC, AdaptCovRandomWalk, AdaptScaleCovRandomWalk,  # noqa: E402
+                                   MetropolisRandomWalk, VanillaHMC)
 
 d, N, T = 100, 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 only = sys.argv[2:]
@@ -25,7 +29,13 @@ th0 = np.random.default_rng(1).standard_normal((N, d)) @ np.linalg.cholesky(Ct).
 C0 = (2.38 ** 2 / d) * np.eye(d)
 for name, p in (("plain", MetropolisRandomWalk(C0)),
                 ("adaptcov float test", AdaptCovRandomWalk(C0, t_adapt=1000, smooth_adapt=True)),
-                ("adaptcov squares", AdaptCovRandomWalk(C0, t_adapt=1000, smooth_adapt=True, exact_squares=True))):
+                ("adaptcov squares", AdaptCovRandomWalk(C0, t_adapt=1000, smooth_adapt=True, exact_squares=True)),
+                ("scalecov float test", AdaptScaleCovRandomWalk(C0, t_adapt=1000, smooth_adapt=True)),
+                ("scalecov squares", AdaptScaleCovRandomWalk(C0, t_adapt=1000, smooth_adapt=True, exact_squares=True)),
+                ("hmc L=2 mass plain", VanillaHMC(0.1, 2, m, M=np.eye(d))),
+                ("hmc L=2 adaptcov float test", AdaptCovHMC(0.1, 2, m, np.eye(d), t_adapt=1000, smooth_adapt=True)),
+                ("hmc L=2 adaptcov squares", AdaptCovHMC(0.1, 2, m, np.eye(d), t_adapt=1000, smooth_adapt=True,
+                                                         exact_squares=True))):
     if only and not any(o in name for o in only):
         continue
     s = ra.Sampler(m, p, th0, seed=3)

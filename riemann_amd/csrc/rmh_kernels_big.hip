@@ -149,13 +149,15 @@ __global__ void __launch_bounds__(256) k_big_rw(GaussArgs m, RwArgs pr, ChainArg
     icdf_stage(tab, ch.icdf);
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // (the wave index as a scalar: every tile / row offset derived from it is then scalar arithmetic)
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int cl = lane & 15, g = lane >> 4;
     // chain blocks of this workgroup; blocks beyond the end repeat the last one and store nothing
     int64_t cj[CB];
     uint32_t vj[CB]; // byte offset of (row g, chain) in a (rows, ld) array
     bool act[CB];
-    const uint32_t ld8 = (uint32_t)ch.ld * 8u;
+    const uint32_t ld8_0 = (uint32_t)ch.ld * 8u;
+    uint32_t ld8 = ld8_0;
 #pragma unroll
     for (int j = 0; j < CB; ++j) {
         int64_t b = (int64_t)blockIdx.x * CB + j;
@@ -202,6 +204,10 @@ __global__ void __launch_bounds__(256) k_big_rw(GaussArgs m, RwArgs pr, ChainArg
 
     for (int64_t t = 0; t < run.T; ++t) {
         asm volatile("" ::: "memory"); // nothing of an iteration is hoisted out of the loop
+        // (nor its row offsets: hoisted, the ~100 offsets ld8 * row of a wave's tiles are spilled before the loop
+        // and reloaded one by one inside it -- every reload a vmcnt(0) drain of the state stores in flight)
+        ld8 = ld8_0;
+        asm volatile("" : "+s"(ld8));
         // 1. waves 0..CB-1: the iteration's normals of their block (two per word, rmh-rng v4)
         if (w < CB) {
             double *Yw = Y + jw * ystride;

@@ -1,3 +1,9 @@
+"""Kernels with scratch traffic INSIDE a loop, from hipcc --cuda-device-only -S assembly files: a scratch reload
+next to memory stores drains the whole in-order vmcnt queue, so these are the spills that cost.
+
+    hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 --cuda-device-only -S riemann_amd/csrc/rmh_kernels_big.hip -o /tmp/k.s
+    python tools/asm_loop_scratch.py /tmp/k.s ...
+"""
 import re,sys,subprocess
 def dem(n):
     return subprocess.run(["c++filt",n],capture_output=True,text=True).stdout.strip()

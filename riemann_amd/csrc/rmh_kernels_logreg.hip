@@ -66,8 +66,12 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
         // Eight waves for every dimension; sixteen at d <= 16 spill 100 registers at the 128 cap.)
         constexpr int NW = 8;
         if constexpr (kNT >= 2) { // d = 16 NF + 1 .. 16 NF + 4: the last column tile of the gradient on the VALU (rmh_models.hpp)
-            if (m.ks == 4 * (kNT - 1) + 1 && r.pt_K == 0 && !p.chM && !c.nmode && !policy(RMH_POLICY_NO_TAIL)) {
+            if (m.ks == 4 * (kNT - 1) + 1 && r.pt_K == 0 && !c.nmode && !policy(RMH_POLICY_NO_TAIL)) {
                 using MT = LogRegModel<(kNT >= 2 ? kNT : 2), true>;   // (kNT = 1 never gets here; the launcher is not a template)
+                if (p.chM) { // with a mass matrix: the same eight-wave evaluation, the triangular products around it
+                    if (adapt) return launch(k_run_hmc<MT, NW, true, true>, c.nblocks, NW, lds, st, m, p, c, r);
+                    return launch(k_run_hmc<MT, NW, false, true>, c.nblocks, NW, lds, st, m, p, c, r);
+                }
                 if (adapt) return launch(k_run_hmc<MT, NW, true, false>, c.nblocks, NW, lds, st, m, p, c, r);
                 return launch(k_run_hmc<MT, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);
             }
@@ -76,9 +80,9 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
             if (p.chM) return launch(k_run_hmc<M, 4, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
             return launch(k_run_hmc<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
         }
-        if (p.chM) { // mass-matrix variant: one wave per SIMD (register budget)
-            if (adapt) return launch(k_run_hmc<M, 4, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
-            return launch(k_run_hmc<M, 4, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
+        if (p.chM) { // mass-matrix variant
+            if (adapt) return launch(k_run_hmc<M, NW, true, true>, c.nblocks, NW, lds, st, m, p, c, r);
+            return launch(k_run_hmc<M, NW, false, true>, c.nblocks, NW, lds, st, m, p, c, r);
         }
         if (adapt) return launch(k_run_hmc<M, NW, true, false>, c.nblocks, NW, lds, st, m, p, c, r);
         return launch(k_run_hmc<M, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);

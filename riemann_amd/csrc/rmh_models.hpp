@@ -227,7 +227,9 @@ struct LogRegModel {
     // w, w+NW, ...; completion = s_waitcnt vmcnt(0), which __syncthreads() issues
     static RMH_DEV void stage(const Args &m, int64_t chunk, double *dst)
     {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        // (the wave index as a SCALAR: piece counter and LDS destination are then scalar arithmetic -- as a vector
+        // value the loop state was spilled in the generic NT = 6, 7 kernels and reloaded inside the stage loop)
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
         const double *src = m.Ximg + chunk * CHD;
         for (int j = wave; j < NP; j += nw)
             __builtin_amdgcn_global_load_lds((glb_void_t *)(src + j * 128 + lane * 2),

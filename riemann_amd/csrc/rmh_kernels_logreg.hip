@@ -76,6 +76,15 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
                 return launch(k_run_hmc<MT, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);
             }
         }
+        if (m.ks == 4 * kNT && r.pt_K == 0 && !policy(RMH_POLICY_NO_TAIL)) { // d = 16 NT: no k-step test inside the eta chains
+            using MF = LogRegModel<kNT, false, true>;
+            if (p.chM) {
+                if (adapt) return launch(k_run_hmc<MF, NW, true, true>, c.nblocks, NW, lds, st, m, p, c, r);
+                return launch(k_run_hmc<MF, NW, false, true>, c.nblocks, NW, lds, st, m, p, c, r);
+            }
+            if (adapt) return launch(k_run_hmc<MF, NW, true, false>, c.nblocks, NW, lds, st, m, p, c, r);
+            return launch(k_run_hmc<MF, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);
+        }
         if (r.pt_K > 0) { // parallel tempering: HMC / MALA (with or without a mass matrix) within the rungs
             if (p.chM) return launch(k_run_hmc<M, 4, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
             return launch(k_run_hmc<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);

@@ -202,9 +202,13 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 // k_run_rw_tail, rmh_run.hpp): lane (g, cl = 4r + c) reads X[row 4r+g][column 16 NF + c] with ONE
 // ds_read_b64, the fmas take it by row broadcast, and every lane accumulates its own data rows'
 // share of the four columns; the chain's four lanes meet once per evaluation (sum4_scatter).
-template <int NT, bool GT = false>
+// FULL (round 3): d = 16 NT exactly, every k-step of eta is real -- the generic kernel decides the last four
+// k-steps of every eta chain by wave-uniform tests (four branches inside a chain of 4 NT MFMAs); as a
+// compile-time fact the chain is straight-line code (d = 32: 2.15 -> 1.97 ms per iteration, d = 64: 3.38 -> 3.16).
+template <int NT, bool GT = false, bool FULL = false>
 struct LogRegModel {
     static_assert(!GT || NT >= 2, "the gradient tail needs at least one full column tile");
+    static_assert(!(GT && FULL), "a dimension is either 16 NT or 16 (NT - 1) + 1..4");
     using Args = LogRegArgs;
     using T = Tile<NT>;
     static constexpr int S = T::S;
@@ -214,7 +218,7 @@ struct LogRegModel {
     static constexpr int NP = CHD / 128;           // 1-KiB DMA pieces per stage
     static constexpr int kTailNF = GT ? NT - 1 : 0; // > 0: d = 16 NF + 1 .. 16 NF + 4 is a compile-time fact
     static constexpr int NG = GT ? NT - 1 : NT;    // gradient row tiles on the matrix core
-    static constexpr int KS = GT ? 4 * (NT - 1) + 1 : 0;   // k-steps of eta when known at compile time
+    static constexpr int KS = GT ? 4 * (NT - 1) + 1 : FULL ? 4 * NT : 0;   // k-steps of eta when known at compile time
 
     static constexpr __host__ __device__ size_t lds_doubles(bool) { return (size_t)2 * CHD + kLogiDoubles; }
     // LDS: [stage 0][stage 1][link-function table]

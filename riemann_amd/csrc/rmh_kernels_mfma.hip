@@ -34,6 +34,10 @@ hipError_t launch_gauss_rw(int NT, const GaussArgs &m, const RwArgs &p, const Ch
         // eight waves give every SIMD a second wavefront to cover the s_waitcnt
         // stalls (LDS table reads of the normals, state/record traffic): +16 %
         constexpr int NW = (kNT >= 5) ? 8 : 4;
+        if (c.d == 16 * kNT && !policy(RMH_POLICY_NO_TAIL)) { // every k-step and stream word is real: compile-time counts
+            if (adapt) return launch(k_run_rw<M, NW, true, false, false, false, true>, c.nblocks, NW, lds, st, m, p, c, r);
+            return launch(k_run_rw<M, NW, false, false, false, false, true>, c.nblocks, NW, lds, st, m, p, c, r);
+        }
         if (adapt) return launch(k_run_rw<M, NW, true, false>, c.nblocks, NW, lds, st, m, p, c, r);
         return launch(k_run_rw<M, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);
     })

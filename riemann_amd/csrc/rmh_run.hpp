@@ -198,11 +198,22 @@ struct PtLane {
 // (neighbouring lanes of the same 16-lane row): no memory traffic.
 // LGLOBAL: the proposal's tile image is read from global memory (L2) instead of LDS
 // (models whose own LDS use leaves no room for it: the logistic regression).
-template <class M, int NW, bool ADAPT, bool PCN = false, bool PT = false, bool LGLOBAL = false>
-__global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m, RwArgs pr, ChainArgs ch, RunArgs run)
+// FULL: d = 16 NT exactly (Gaussian model).  The dimension's k-step and word counts are then compile-time
+// constants: no wave-uniform test in front of the last four k-steps of every triangular product, no
+// coordinate selects in the normals (as the VALU-tail kernels have it for d = 16 NF + 1..4).
+template <class M, int NW, bool ADAPT, bool PCN = false, bool PT = false, bool LGLOBAL = false, bool FULL = false>
+__global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m_in, RwArgs pr, ChainArgs ch_in, RunArgs run)
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
     using T = Tile<NT>;
+    typename M::Args m = m_in;
+    ChainArgs ch = ch_in;
+    if constexpr (FULL) {
+        ch.d = 4 * S;
+        ch.ks = S;
+        ch.M = S / 2;
+        m.ks = S;
+    }
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const double *Limg = LGLOBAL ? pr.Ltiles : lds;
     double *mlds = lds + (LGLOBAL ? 0 : tri_tiles(NT) * 64);

@@ -811,6 +811,59 @@ def test_tail_kernel_variants_vs_oracle_and_generic_kernel(ra, orc, d):
     np.testing.assert_allclose(t[3], ht, rtol=RTOL, atol=1e-12)
 
 
+@pytest.mark.parametrize("d", [16, 32, 48, 64, 80, 96, 112])
+def test_exact_multiple_of_16_kernels_vs_oracle_and_generic_kernel(ra, orc, d):
+    """d = 16 NT: k_run_rw<..., FULL> (Gaussian random walk, plain and adapted scale) and
+    LogRegModel<NT, false, FULL> (MALA, HMC with and without a mass matrix, adapted scale) carry the k-step
+    and word counts as compile-time constants.  Same arithmetic in the same order as the generic kernels
+    (kernel policy NO_TAIL): bit-identical to them, and against the oracle."""
+    from riemann_amd._lib import kernel_policy
+    from riemann_amd.models import LogisticRegression, MultiGaussianDist
+    from riemann_amd.proposals import MALA, AdaptScaleHMC, AdaptScaleRandomWalk, MetropolisRandomWalk, VanillaHMC
+    from riemann_amd.workloads import logreg_data
+    g = np.random.default_rng(2000 + d)
+    A = g.standard_normal((d, d))
+    Ct = A @ A.T / d + 0.3 * np.eye(d)
+    mu = g.standard_normal(d)
+    Cp = (2.38 ** 2 / d) * Ct
+    B = g.standard_normal((d, d))
+    Mm = B @ B.T / d + np.eye(d)
+    th0 = mu + g.standard_normal((150, d))
+    gm, om = MultiGaussianDist(mu, Ct), orc.Gaussian(mu, Ct)
+    X, y = logreg_data(300, d, seed=d)
+    lm, olm = LogisticRegression(X, y, 50.0), orc.LogReg(X, y, 50.0)
+    tl0 = 0.05 * g.standard_normal((150, d))
+    out = {}
+    for pol in ((), ("NO_TAIL",)):
+        with kernel_policy(*pol):
+            runs = [ra.Sampler(gm, MetropolisRandomWalk(Cp), th0, seed=5, chain0=32),
+                    ra.Sampler(gm, AdaptScaleRandomWalk(Cp), th0, seed=6),
+                    ra.Sampler(lm, MALA(0.1, lm), tl0, seed=7),
+                    ra.Sampler(lm, VanillaHMC(0.06, 3, lm, M=Mm), tl0, seed=8),
+                    ra.Sampler(lm, AdaptScaleHMC(0.08, 2, lm), tl0, seed=9)]
+            for s, T in zip(runs, (12, 25, 8, 5, 10)):
+                s.run(T)
+            out[pol] = [(s._chain_accept.copy(), s._chain_thetas.copy(), s._chain_logpost.copy()) for s in runs]
+    for t, gnr in zip(out[()], out[("NO_TAIL",)]):
+        for a, b in zip(t, gnr):
+            np.testing.assert_array_equal(a, b)
+    ht, hl, acc = oracle_run(orc, om, orc.RandomWalk(Cp), th0, 5, 12, chain0=32)
+    np.testing.assert_array_equal(out[()][0][0], acc)
+    np.testing.assert_allclose(out[()][0][1], ht, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(out[()][0][2], hl, rtol=RTOL)
+    th, st, ad = th0.copy(), orc.rng_seed(6, 150), orc.new_adapt_state(150)
+    ht, hl, acc = orc.run(om, orc.set_adapt(orc.RandomWalk(Cp), 0.25), th, om.log_posterior(th), st, 25, adapt=ad)
+    np.testing.assert_array_equal(out[()][1][0], acc)
+    np.testing.assert_allclose(out[()][1][1], ht, rtol=RTOL, atol=1e-12)
+    ht, hl, acc = oracle_run(orc, olm, orc.HMC(0.1, 1, d), tl0, 7, 8)
+    np.testing.assert_array_equal(out[()][2][0], acc)
+    np.testing.assert_allclose(out[()][2][1], ht, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(out[()][2][2], hl, rtol=RTOL)
+    ht, hl, acc = oracle_run(orc, olm, orc.HMC(0.06, 3, d, M=Mm), tl0, 8, 5)
+    np.testing.assert_array_equal(out[()][3][0], acc)
+    np.testing.assert_allclose(out[()][3][1], ht, rtol=1e-8, atol=1e-10)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["rw", "mala", "cp", "adaptcov", "bigd"])
 def test_unrecorded_run_ends_in_the_last_kept_state(ra, kind):

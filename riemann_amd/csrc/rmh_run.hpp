@@ -718,6 +718,9 @@ struct MomFused {
 template <int NF, int NW, bool ADAPT = false, bool PT = false, bool MOM = false>
 __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
+    // log's constants as opaque literals (rmh_device.hpp log_pos<OPQ>): hoisted out of the iteration loop they
+    // are five more live register pairs -- spilled, and reloaded inside the loop, in these variants
+    constexpr bool kOpaqueLog = MOM || (NF == 5 && !ADAPT && !PT);
     constexpr int NT = NF + 1, S = 4 * NT, kFull = tri_tiles(NF) * 64; // NF full row tiles (NF = 6: 84 tile images)
     constexpr int kTD = tail_doubles(NF), KS = tail_ksteps(NF);   // KS k-steps carry coordinates
     using T = Tile<NT>;
@@ -832,7 +835,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         const double u = T::accept_uniform(rng, g, cl);
         // (MOM: the logarithm's constants as literals at their use -- hoisted to kernel entry they are
         // spilled there, and a scratch reload in the loop waits for every store in flight)
-        bool acc_ok = mh_accept<MOM>(lpp, lp, 0.0, u);
+        bool acc_ok = mh_accept<kOpaqueLog>(lpp, lp, 0.0, u);
         if (PT) acc_ok = pt.within(acc_ok);
 #pragma unroll
         for (int s = 0; s < S; ++s) th[s] = acc_ok ? thp[s] : th[s];

@@ -191,9 +191,9 @@ int rmh_state_set_rng(rmh_state_t s, const uint64_t *rng);
  * proposals/hamiltonian.py:79 draws float64 values).  mode 0 (default): two normals per 64-bit stream
  * word, each the quantile of a 32-bit half word (a lattice of 2^-27 in p inside a cell, |z| <= 6.4);
  * mode 1: ONE normal per word -- 52 bits inside a cell, p down to 2^-58 (|z| <= 8.6), the quantile map
- * good to 2.1e-16 -- at twice the stream words and a longer table evaluation; served by the generic
- * kernels (the d = 16 NF + 1..4 tail kernels, the specialised changepoint kernels, d > 112 and the
- * variable-k model are 32-bit only: the first two are routed around, the last two refuse). */
+ * good to 2.1e-16 -- at twice the stream words and a longer table evaluation; served by every kernel
+ * family except the specialised changepoint kernels (routed to the generic one), d > 112 and the
+ * variable-k / block-mixture proposals (refused). */
 int rmh_state_set_normal_mode(rmh_state_t s, int mode);
 int rmh_state_get_normal_mode(rmh_state_t s, int *mode);
 int rmh_state_get_adapt(rmh_state_t s, double *adapt);       /* (N,3) */

@@ -66,8 +66,12 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
         // Eight waves for every dimension; sixteen at d <= 16 spill 100 registers at the 128 cap.)
         constexpr int NW = 8;
         if constexpr (kNT >= 2) { // d = 16 NF + 1 .. 16 NF + 4: the last column tile of the gradient on the VALU (rmh_models.hpp)
-            if (m.ks == 4 * (kNT - 1) + 1 && r.pt_K == 0 && !c.nmode && !policy(RMH_POLICY_NO_TAIL)) {
+            if (m.ks == 4 * (kNT - 1) + 1 && r.pt_K == 0 && !(c.nmode && p.chM) && !policy(RMH_POLICY_NO_TAIL)) {
                 using MT = LogRegModel<(kNT >= 2 ? kNT : 2), true>;   // (kNT = 1 never gets here; the launcher is not a template)
+                if (c.nmode) { // the 64-bit normal mode (its draw as a compile-time variant; with a mass matrix: the generic kernel)
+                    if (adapt) return launch(k_run_hmc<MT, NW, true, false, false, true>, c.nblocks, NW, lds, st, m, p, c, r);
+                    return launch(k_run_hmc<MT, NW, false, false, false, true>, c.nblocks, NW, lds, st, m, p, c, r);
+                }
                 if (p.chM) { // with a mass matrix: the same eight-wave evaluation, the triangular products around it
                     if (adapt) return launch(k_run_hmc<MT, NW, true, true>, c.nblocks, NW, lds, st, m, p, c, r);
                     return launch(k_run_hmc<MT, NW, false, true>, c.nblocks, NW, lds, st, m, p, c, r);

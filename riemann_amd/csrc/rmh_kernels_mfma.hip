@@ -52,7 +52,12 @@ static hipError_t gauss_rw_tail_launch(const GaussArgs &m, const RwArgs &p, cons
 {
     // as the generic kernels: eight waves once the tile images fill most of a CU's LDS
     constexpr int NW = (NF >= 4) ? 8 : 4;
-    const size_t lds = sizeof(double) * (2 * tri_tiles(NF) * 64 + 2 * tail_doubles(NF) + 4 * 4 * (NF + 1) + kIcdfDoubles);
+    const size_t lds = sizeof(double) * (2 * tri_tiles(NF) * 64 + 2 * tail_doubles(NF) + 4 * 4 * (NF + 1) + icdf_doubles(c.nmode));
+    if (c.nmode) { // the 64-bit normal mode: plain and adapted-scale walks (the callers route tempering and the fused moments around)
+        if (r.mom_partial || r.pt_K > 0) return hipErrorInvalidValue;
+        if (adapt) return launch(k_run_rw_tail<NF, NW, true, false, false, true>, c.nblocks, NW, lds, st, m, p, c, r);
+        return launch(k_run_rw_tail<NF, NW, false, false, false, true>, c.nblocks, NW, lds, st, m, p, c, r);
+    }
     if (r.mom_partial) { // AdaptCov: the pooled moments of the states 1..T accumulated in the kernel
         if constexpr (NF == 6) {
             if (r.pt_K > 0 || adapt) return hipErrorInvalidValue;

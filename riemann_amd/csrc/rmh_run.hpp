@@ -715,7 +715,8 @@ struct MomFused {
     }
 };
 
-template <int NF, int NW, bool ADAPT = false, bool PT = false, bool MOM = false>
+// N64: the 64-bit-resolution normal mode (one normal per stream word, rmh_device.hpp) with its longer table in LDS
+template <int NF, int NW, bool ADAPT = false, bool PT = false, bool MOM = false, bool N64 = false>
 __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
     // log's constants as opaque literals (rmh_device.hpp log_pos<OPQ>): hoisted out of the iteration loop they
@@ -729,8 +730,9 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
     double *Lt = Wimg + kFull, *Wt = Lt + kTD;
     double *mu = Wt + kTD;
     double *tab = mu + 4 * S;
-    double *panels = tab + kIcdfDoubles;   // MOM: two 16-chain panels (MomFused)
-    static_assert(!MOM || (NF == 6 && NW == 8 && !ADAPT && !PT), "MomFused: d = 97..100, eight wavefronts, plain random walk");
+    double *panels = tab + icdf_doubles(N64 ? 1 : 0);   // MOM: two 16-chain panels (MomFused)
+    static_assert(!MOM || (NF == 6 && NW == 8 && !ADAPT && !PT && !N64), "MomFused: d = 97..100, eight wavefronts, plain random walk");
+    static_assert(!N64 || !PT, "the 64-bit normal mode of the tail kernels: plain and adapted-scale walks");
     for (int i = threadIdx.x; i < kFull; i += blockDim.x) {
         Limg[i] = pr.Ltiles[i];
         Wimg[i] = m.Wtiles[i];
@@ -740,7 +742,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         Wt[i] = m.Wtail[i];
     }
     for (int i = threadIdx.x; i < 4 * S; i += blockDim.x) mu[i] = m.mu_pad[i];
-    icdf_stage(tab, ch.icdf);
+    icdf_stage(tab, ch.icdf, N64 ? 1 : 0);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -794,7 +796,10 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
         if (PT) pt.select(run, rng, cl);
         double xi[S];
         // d = 16 NF + 1 .. 16 NF + 4: 2 NF + 1 words per sub-stream, as compile-time constants
-        T::template normals_fixed<2 * NF + 1, 16 * NF + 4, (MOM || NF < 4) ? 2 : 3>(rng, ch.d, g, tab, xi);
+        if constexpr (N64) {
+            __builtin_assume(ch.d > 16 * NF && ch.d <= 16 * NF + 4);   // only the last k-step's coordinates can lie beyond d
+            T::normals64(rng, KS, ch.d, g, tab, xi);
+        } else T::template normals_fixed<2 * NF + 1, 16 * NF + 4, (MOM || NF < 4) ? 2 : 3>(rng, ch.d, g, tab, xi);
         // theta' = theta + scale * L xi: row tiles 0..5 on the matrix core, rows 96..99 on the VALU
         // (ADAPT: the chain's own scale times the unscaled image's product, as in k_run_rw)
         double4_t acc[NF];
@@ -883,7 +888,9 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
 // the rung (samplers/ptsampler.py:82 hands every rung the same proposal) -- and only the accept
 // test sees the tempered posterior.  A swap exchanges the two replicas' states and cached
 // gradients in global memory.
-template <class M, int NW, bool ADAPT, bool MASS, bool PT = false>
+// N64 (models with a compile-time stream length only, M::kTailNF > 0): the draw of the 64-bit normal mode in place of
+// normals_fixed -- as a template parameter so that the 32-bit kernels keep their register allocation
+template <class M, int NW, bool ADAPT, bool MASS, bool PT = false, bool N64 = false>
 __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs pr, ChainArgs ch, RunArgs run)
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
@@ -962,7 +969,10 @@ __global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs
         if (t < run.T) {
             // d = 16 NF + 1 .. 16 NF + 4 (the model's compile-time case): 2 NF + 1 words per sub-stream,
             // no wave-uniform word and k-step predicates (rmh_mfma.hpp)
-            if constexpr (M::kTailNF > 0) T::template normals_fixed<2 * M::kTailNF + 1, 16 * M::kTailNF + 4>(rng, ch.d, g, tab, p);
+            if constexpr (M::kTailNF > 0 && N64) {
+                __builtin_assume(ch.d > 16 * M::kTailNF && ch.d <= 16 * M::kTailNF + 4);
+                T::normals64(rng, 4 * M::kTailNF + 1, ch.d, g, tab, p);
+            } else if constexpr (M::kTailNF > 0) T::template normals_fixed<2 * M::kTailNF + 1, 16 * M::kTailNF + 4>(rng, ch.d, g, tab, p);
             else T::normals_mode(ch.nmode, rng, ch.M, ch.ks, ch.d, g, tab, p);
         }
         T::load_state(ch.theta, ch.ld, c, g, q);

@@ -195,8 +195,9 @@ static int acov_update(rmh_proposal *p)
     return sync_proposal(p);
 }
 
-// the VALU-tail kernels draw a compile-time number of 32-bit-resolution normals: not in the 64-bit normal mode
-static bool tail_ok(const ChainArgs &c) { return !c.nmode && !policy(RMH_POLICY_NO_TAIL); }
+// (the VALU-tail kernels serve the 64-bit normal mode for the plain and adapted-scale walks: not within tempering,
+// not with the moments fused in)
+static bool tail_ok(const ChainArgs &) { return !policy(RMH_POLICY_NO_TAIL); }
 
 // adapt: the AdaptScale variant (per-chain scale in c.adapt, unscaled tile image)
 static hipError_t launch_rw_plain(rmh_model *m, rmh_proposal *p, const ChainArgs &c, const RunArgs &r, bool adapt)
@@ -236,7 +237,7 @@ static int run_adaptcov(rmh_model *m, rmh_proposal *p, rmh_state *s, const Chain
     int rc;
     const int64_t rows = 4 * s->ks, ld = s->ld;
     const bool fused = p->kind == kRW && m->kind == kGauss && m->ga.Wtail && p->d_Ltail && !c.adapt &&
-                       p->acov_NT == 7 && tail_ok(c) && !policy(RMH_POLICY_ACOV_UNFUSED);
+                       p->acov_NT == 7 && tail_ok(c) && !c.nmode && !policy(RMH_POLICY_ACOV_UNFUSED);
     int mom_passes = 1;
     const int64_t nwg = fused ? gauss_rw_tail_mom_grid(c.nblocks, &mom_passes) : kAcovWGs;
     const size_t need = (size_t)nwg * acov_ntri(p) * 256;
@@ -452,7 +453,7 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
                                       : launch_mix_pcn(m->NT, m->ma, ra, c, r, false, g_stream);
     } else if (K > 0) {
         RwArgs ra{p->d_Ltiles, nullptr, 0.0};
-        const bool tail = m->kind == kGauss && m->ga.Wtail && p->d_Ltail && tail_ok(c);
+        const bool tail = m->kind == kGauss && m->ga.Wtail && p->d_Ltail && tail_ok(c) && !c.nmode;
         if (tail) ra.Ltail = p->d_Ltail;
         e = tail                      ? launch_gauss_rw_tail(m->ga, ra, c, r, false, g_stream)
             : m->kind == kGauss       ? launch_gauss_pt(m->NT, m->ga, ra, c, r, g_stream)

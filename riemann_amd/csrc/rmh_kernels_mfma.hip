@@ -60,10 +60,13 @@ static hipError_t gauss_rw_tail_launch(const GaussArgs &m, const RwArgs &p, cons
     }
     if (r.mom_partial) { // AdaptCov: the pooled moments of the states 1..T accumulated in the kernel
         if constexpr (NF == 6) {
-            if (r.pt_K > 0 || adapt) return hipErrorInvalidValue;
+            if (r.pt_K > 0) return hipErrorInvalidValue;
             int passes = 1;
             const int64_t grid = gauss_rw_tail_mom_grid(c.nblocks, &passes);
             if (passes != r.mom_passes) return hipErrorInvalidValue;
+            if (adapt) // AdaptScaleCovRandomWalk: the chains' own scales between the pooled covariance updates
+                return launch(k_run_rw_tail<6, 8, true, false, true>, grid * 8, 8, lds + sizeof(double) * 2 * kMomPanel,
+                              st, m, p, c, r);
             return launch(k_run_rw_tail<6, 8, false, false, true>, grid * 8, 8, lds + sizeof(double) * 2 * kMomPanel,
                           st, m, p, c, r);
         }

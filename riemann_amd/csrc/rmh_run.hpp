@@ -731,7 +731,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
     double *mu = Wt + kTD;
     double *tab = mu + 4 * S;
     double *panels = tab + icdf_doubles(N64 ? 1 : 0);   // MOM: two 16-chain panels (MomFused)
-    static_assert(!MOM || (NF == 6 && NW == 8 && !ADAPT && !PT && !N64), "MomFused: d = 97..100, eight wavefronts, plain random walk");
+    static_assert(!MOM || (NF == 6 && NW == 8 && !PT && !N64), "MomFused: d = 97..100, eight wavefronts, random walk (plain or adapted scale)");
     static_assert(!N64 || !PT, "the 64-bit normal mode of the tail kernels: plain and adapted-scale walks");
     for (int i = threadIdx.x; i < kFull; i += blockDim.x) {
         Limg[i] = pr.Ltiles[i];

@@ -236,7 +236,7 @@ static int run_adaptcov(rmh_model *m, rmh_proposal *p, rmh_state *s, const Chain
 {
     int rc;
     const int64_t rows = 4 * s->ks, ld = s->ld;
-    const bool fused = p->kind == kRW && m->kind == kGauss && m->ga.Wtail && p->d_Ltail && !c.adapt &&
+    const bool fused = p->kind == kRW && m->kind == kGauss && m->ga.Wtail && p->d_Ltail &&
                        p->acov_NT == 7 && tail_ok(c) && !c.nmode && !policy(RMH_POLICY_ACOV_UNFUSED);
     int mom_passes = 1;
     const int64_t nwg = fused ? gauss_rw_tail_mom_grid(c.nblocks, &mom_passes) : kAcovWGs;
@@ -288,7 +288,7 @@ static int run_adaptcov(rmh_model *m, rmh_proposal *p, rmh_state *s, const Chain
             r.mom_passes = mom_passes;
             RwArgs ra{p->d_Ltiles, nullptr, 0.0};
             ra.Ltail = p->d_Ltail;
-            RMH_HIP(launch_gauss_rw_tail(m->ga, ra, c, r, false, g_stream));
+            RMH_HIP(launch_gauss_rw_tail(m->ga, ra, c, r, c.adapt != nullptr, g_stream));   // (AdaptScaleCov: the chains' own scales)
             ++*launches;
             // adapt() after every step: the states 1..seg of the stretch, summed over the workgroups
             RMH_HIP(launch_moments_reduce(p->d_acov_partial, nwg, acov_ntri(p) * 256, p->d_acov_acc, g_stream));

@@ -356,16 +356,17 @@ def test_adaptive_covariance_run_of_zero_steps(ra):
     np.testing.assert_array_equal(s._chain_thetas[0], th0)
 
 
-@pytest.mark.parametrize("d,N,squares", [(100, 333, False), (97, 2100, True)])
-def test_adaptive_covariance_fused_moments_vs_scratch_history(ra, d, N, squares):
+@pytest.mark.parametrize("d,N,squares,scale", [(100, 333, False, False), (97, 2100, True, False), (99, 500, False, True)])
+def test_adaptive_covariance_fused_moments_vs_scratch_history(ra, d, N, squares, scale):
     """d = 97..100: the sampling kernel accumulates the pooled moments itself (MomFused,
     rmh_run.hpp) and records straight into the caller's history; policy ACOV_UNFUSED keeps
     round 2's scratch history + k_moments.  Same stream, same schedule: accept masks equal, states
     and the adapted covariance equal to the rounding of two summation orders -- with burn-in and
-    thinning across update boundaries, without a history, and over a run-after-run sequence."""
+    thinning across update boundaries, without a history, and over a run-after-run sequence.
+    scale: AdaptScaleCovRandomWalk, the chains' own scale adaptation inside the same fused kernel."""
     from riemann_amd._lib import kernel_policy
     from riemann_amd.models import MultiGaussianDist
-    from riemann_amd.proposals import AdaptCovRandomWalk
+    from riemann_amd.proposals import AdaptCovRandomWalk, AdaptScaleCovRandomWalk
     g = np.random.default_rng(d * N)
     A = g.standard_normal((d, d))
     Ct = A @ A.T / d + 0.3 * np.eye(d)
@@ -375,7 +376,8 @@ def test_adaptive_covariance_fused_moments_vs_scratch_history(ra, d, N, squares)
     out = []
     for pol in ((), ("ACOV_UNFUSED",)):
         with kernel_policy(*pol):
-            p = AdaptCovRandomWalk(C0, t_adapt=30, smooth_adapt=True, exact_squares=squares)
+            cls = AdaptScaleCovRandomWalk if scale else AdaptCovRandomWalk
+            p = cls(C0, t_adapt=30, smooth_adapt=True, exact_squares=squares)
             s = ra.Sampler(m, p, th0, seed=5, chain0=48)
             s.run(37)
             r1 = (s._chain_accept.copy(), s._chain_thetas.copy(), s._chain_logpost.copy())
@@ -383,7 +385,8 @@ def test_adaptive_covariance_fused_moments_vs_scratch_history(ra, d, N, squares)
             r2 = (s._chain_accept.copy(), s._chain_thetas.copy(), s._chain_logpost.copy())
             s.run(23, record=False)
             th, lp = s.current_state()
-            out.append((r1, r2, np.array(th), np.array(lp), p.C.copy(), p.L.copy(), p._SX.copy()))
+            out.append((r1, r2, np.array(th), np.array(lp), p.C.copy(), p.L.copy(), p._SX.copy(),
+                        np.array(p.scale).copy()))
     a, b = out
     for k in (0, 1):
         np.testing.assert_array_equal(a[k][0], b[k][0])
@@ -394,6 +397,7 @@ def test_adaptive_covariance_fused_moments_vs_scratch_history(ra, d, N, squares)
     np.testing.assert_allclose(a[4], b[4], rtol=1e-9, atol=1e-15)
     np.testing.assert_allclose(a[5], b[5], rtol=1e-8, atol=1e-14)
     np.testing.assert_allclose(a[6], b[6], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(a[7], b[7], rtol=1e-12)
 
 
 def test_stand_alone_propose_of_the_covariance_adaptive_walks(ra):

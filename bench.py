@@ -92,7 +92,9 @@ def workload(name, chains):
                     oprop=lambda o: o.RandomWalk(np.diag(cdiag), 0.1),
                     batched=lambda b: (b.BatchChangepoint(x, y, k, 1.0, 3.0, 5.0, 1.0, 1.0),
                                        dict(L_prop=0.1 * np.diag(np.sqrt(cdiag))), 16384, 60),
-                    ess_run=(200000, 200),      # tau_int ~ 2.7e3 iterations: a long thinned trace
+                    # the slowest changepoint position does not decorrelate at these lengths: tau_int 1.2e4 from 2e5 iterations,
+                    # 7.4e4 from 2e6 (window not closed either time, reported as such): the longer, more conservative trace
+                    ess_run=(2000000, 2000),
                     cpu_sample=(65536, 1000))
     if name == "pt_gauss":      # PTSampler, default ladder, on the cfg2 target
         d, K = 100, 5

@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
 {
     // log's constants as opaque literals (rmh_device.hpp log_pos<OPQ>): hoisted out of the iteration loop they
     // are five more live register pairs -- spilled, and reloaded inside the loop, in these variants
-    constexpr bool kOpaqueLog = MOM || (NF == 5 && !ADAPT && !PT);
+    constexpr bool kOpaqueLog = MOM || (NF == 5 && !ADAPT && !PT) || (NF == 6 && (PT || ADAPT));
     constexpr int NT = NF + 1, S = 4 * NT, kFull = tri_tiles(NF) * 64; // NF full row tiles (NF = 6: 84 tile images)
     constexpr int kTD = tail_doubles(NF), KS = tail_ksteps(NF);   // KS k-steps carry coordinates
     using T = Tile<NT>;

@@ -819,7 +819,8 @@ def test_exact_multiple_of_16_kernels_vs_oracle_and_generic_kernel(ra, orc, d):
     (kernel policy NO_TAIL): bit-identical to them, and against the oracle."""
     from riemann_amd._lib import kernel_policy
     from riemann_amd.models import LogisticRegression, MultiGaussianDist
-    from riemann_amd.proposals import MALA, AdaptScaleHMC, AdaptScaleRandomWalk, MetropolisRandomWalk, VanillaHMC
+    from riemann_amd.proposals import MALA, AdaptScaleHMC, AdaptScaleRandomWalk, MetropolisRandomWalk, VanillaHMC, pCN
+    from riemann_amd.samplers import PTSampler
     from riemann_amd.workloads import logreg_data
     g = np.random.default_rng(2000 + d)
     A = g.standard_normal((d, d))
@@ -844,6 +845,13 @@ def test_exact_multiple_of_16_kernels_vs_oracle_and_generic_kernel(ra, orc, d):
             for s, T in zip(runs, (12, 25, 8, 5, 10)):
                 s.run(T)
             out[pol] = [(s._chain_accept.copy(), s._chain_thetas.copy(), s._chain_logpost.copy()) for s in runs]
+            # pCN and the tempered walk on the Gaussian model (k_run_rw<..., PCN / PT, ..., FULL>)
+            pc = ra.Sampler(gm, pCN(1.5 * Ct, 0.95), th0, seed=10)
+            pc.run(10)
+            pt = PTSampler(gm, MetropolisRandomWalk(Cp), th0[:40], betas=0.6 ** np.arange(4), Pswap=0.3, seed=11)
+            pt.run(15)
+            out[pol].append((pc._chain_accept.copy(), pc._chain_thetas.copy(), pc._chain_logpost.copy()))
+            out[pol].append((pt._host_codes.copy(), pt._host_thetas.copy(), pt._host_logpost.copy()))
     for t, gnr in zip(out[()], out[("NO_TAIL",)]):
         for a, b in zip(t, gnr):
             np.testing.assert_array_equal(a, b)
@@ -862,6 +870,9 @@ def test_exact_multiple_of_16_kernels_vs_oracle_and_generic_kernel(ra, orc, d):
     ht, hl, acc = oracle_run(orc, olm, orc.HMC(0.06, 3, d, M=Mm), tl0, 8, 5)
     np.testing.assert_array_equal(out[()][3][0], acc)
     np.testing.assert_allclose(out[()][3][1], ht, rtol=1e-8, atol=1e-10)
+    ht, hl, acc = oracle_run(orc, om, orc.PCN(1.5 * Ct, 0.95), th0, 10, 10)
+    np.testing.assert_array_equal(out[()][5][0], acc)
+    np.testing.assert_allclose(out[()][5][1], ht, rtol=RTOL, atol=1e-12)
 
 
 @pytest.mark.gpu

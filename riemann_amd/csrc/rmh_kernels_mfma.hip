@@ -146,12 +146,13 @@ hipError_t launch_gauss_hmc(int NT, const GaussArgs &m, const HmcArgs &p, const 
             if (p.chM) return launch(k_run_hmc<M, 4, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
             return launch(k_run_hmc<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
         }
+        // (compile-time k-step counts at d = 16 NT and d = 16 (NT - 1) + 1 .. 4: launch_hmc_ks, rmh_launch.hpp)
         if (p.chM) {
-            if (adapt) return launch(k_run_hmc<M, 4, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
-            return launch(k_run_hmc<M, 4, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
+            if (adapt) return launch_hmc_ks<M, 4, true, true>(m, p, c, r, lds, st);
+            return launch_hmc_ks<M, 4, false, true>(m, p, c, r, lds, st);
         }
-        if (adapt) return launch(k_run_hmc<M, 4, true, false>, c.nblocks, 4, lds, st, m, p, c, r);
-        return launch(k_run_hmc<M, 4, false, false>, c.nblocks, 4, lds, st, m, p, c, r);
+        if (adapt) return launch_hmc_ks<M, 4, true, false>(m, p, c, r, lds, st);
+        return launch_hmc_ks<M, 4, false, false>(m, p, c, r, lds, st);
     })
 }
 

@@ -31,8 +31,8 @@ hipError_t launch_mix_hmc(int NT, const MixArgs &m, const HmcArgs &p, const Chai
             if (adapt) return launch(k_run_hmc<M, 4, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
             return launch(k_run_hmc<M, 4, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
         }
-        if (adapt) return launch(k_run_hmc<M, 4, true, false>, c.nblocks, 4, lds, st, m, p, c, r);
-        return launch(k_run_hmc<M, 4, false, false>, c.nblocks, 4, lds, st, m, p, c, r);
+        if (adapt) return launch_hmc_ks<M, 4, true, false, false>(m, p, c, r, lds, st);
+        return launch_hmc_ks<M, 4, false, false, false>(m, p, c, r, lds, st);
     })
 }
 

@@ -890,11 +890,23 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw_tail(GaussArgs m, RwArgs pr,
 // gradients in global memory.
 // N64 (models with a compile-time stream length only, M::kTailNF > 0): the draw of the 64-bit normal mode in place of
 // normals_fixed -- as a template parameter so that the 32-bit kernels keep their register allocation
-template <class M, int NW, bool ADAPT, bool MASS, bool PT = false, bool N64 = false>
-__global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m, HmcArgs pr, ChainArgs ch, RunArgs run)
+// KSC > 0: the dimension's k-step count ceil(d/4) as a compile-time constant (KSC = 4 NT: d = 16 NT exactly, then the
+// word count and d itself too) -- no wave-uniform test in front of the last k-steps of every triangular product
+template <class M, int NW, bool ADAPT, bool MASS, bool PT = false, bool N64 = false, int KSC = 0>
+__global__ void __launch_bounds__(64 * NW) k_run_hmc(typename M::Args m_in, HmcArgs pr, ChainArgs ch_in, RunArgs run)
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
     using T = Tile<NT>;
+    typename M::Args m = m_in;
+    ChainArgs ch = ch_in;
+    if constexpr (KSC > 0) {
+        ch.ks = KSC;
+        m.ks = KSC;
+        if constexpr (KSC == S) {
+            ch.d = 4 * S;
+            ch.M = S / 2;
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *tab = lds + M::lds_doubles(true);
     M::setup(lds, m, true);

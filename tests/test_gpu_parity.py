@@ -875,6 +875,46 @@ def test_exact_multiple_of_16_kernels_vs_oracle_and_generic_kernel(ra, orc, d):
     np.testing.assert_allclose(out[()][5][1], ht, rtol=RTOL, atol=1e-12)
 
 
+@pytest.mark.parametrize("d", [16, 20, 36, 48, 52, 68, 84, 96, 100, 112])
+def test_hmc_kernels_with_compile_time_kstep_counts_vs_generic_kernel_and_oracle(ra, orc, d):
+    """k_run_hmc<..., KSC> (launch_hmc_ks): Gaussian MALA / HMC with a mass matrix / adapted-scale HMC at d = 16 NT and
+    d = 16 (NT - 1) + 1 .. 4, mixture MALA at the latter -- bit-identical to the generic kernels (kernel policy NO_TAIL),
+    MALA against the oracle."""
+    from riemann_amd._lib import kernel_policy
+    from riemann_amd.models import MixtureDist, MultiGaussianDist
+    from riemann_amd.proposals import MALA, AdaptScaleHMC, VanillaHMC
+    g = np.random.default_rng(3000 + d)
+    A = g.standard_normal((d, d))
+    Ct = A @ A.T / d + 0.3 * np.eye(d)
+    B = g.standard_normal((d, d))
+    Mm = B @ B.T / d + np.eye(d)
+    mu = g.standard_normal(d)
+    th0 = mu + g.standard_normal((150, d))
+    gm, om = MultiGaussianDist(mu, Ct), orc.Gaussian(mu, Ct)
+    comps = [(0.4, mu - 0.3, Ct), (0.6, mu + 0.3, 1.5 * Ct)]
+    mm = MixtureDist([[w, MultiGaussianDist(m_, C_)] for w, m_, C_ in comps])
+    out = {}
+    for pol in ((), ("NO_TAIL",)):
+        with kernel_policy(*pol):
+            runs = [ra.Sampler(gm, MALA(0.3, gm), th0, seed=5, chain0=16),
+                    ra.Sampler(gm, VanillaHMC(0.2, 3, gm, M=Mm), th0, seed=6),
+                    ra.Sampler(gm, AdaptScaleHMC(0.2, 2, gm), th0, seed=7),
+                    ra.Sampler(mm, MALA(0.3, mm), th0, seed=8)]
+            for s, T in zip(runs, (10, 6, 12, 8)):
+                s.run(T)
+            out[pol] = [(s._chain_accept.copy(), s._chain_thetas.copy(), s._chain_logpost.copy()) for s in runs]
+    for t, gnr in zip(out[()], out[("NO_TAIL",)]):
+        for a, b in zip(t, gnr):
+            np.testing.assert_array_equal(a, b)
+    ht, hl, acc = oracle_run(orc, om, orc.HMC(0.3, 1, d), th0, 5, 10, chain0=16)
+    np.testing.assert_array_equal(out[()][0][0], acc)
+    np.testing.assert_allclose(out[()][0][1], ht, rtol=1e-8, atol=1e-10)
+    assert 0.05 < acc.mean() <= 1.0
+    ht, hl, acc = oracle_run(orc, orc.Mixture(comps), orc.HMC(0.3, 1, d), th0, 8, 8)
+    np.testing.assert_array_equal(out[()][3][0], acc)
+    np.testing.assert_allclose(out[()][3][1], ht, rtol=1e-8, atol=1e-10)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["rw", "mala", "cp", "adaptcov", "bigd"])
 def test_unrecorded_run_ends_in_the_last_kept_state(ra, kind):

@@ -125,14 +125,14 @@ hipError_t launch_gauss_pcn(int NT, const GaussArgs &m, const RwArgs &p, const C
     RMH_NT_DISPATCH(NT, {
         using M = GaussModel<kNT>;
         const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + M::lds_doubles(false) + icdf_doubles(c.nmode));
-        if (c.d == 16 * kNT && !policy(RMH_POLICY_NO_TAIL)) {   // compile-time k-step and word counts (k_run_rw FULL)
-            if (r.pt_K > 0) return launch(k_run_rw<M, 4, false, true, true, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
-            if (adapt) return launch(k_run_rw<M, 4, true, true, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
-            return launch(k_run_rw<M, 4, false, true, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
+        if (r.pt_K > 0) {
+            if (c.d == 16 * kNT && !policy(RMH_POLICY_NO_TAIL))   // compile-time k-step and word counts (k_run_rw FULL)
+                return launch(k_run_rw<M, 4, false, true, true, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
+            return launch(k_run_rw<M, 4, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
         }
-        if (r.pt_K > 0) return launch(k_run_rw<M, 4, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
-        if (adapt) return launch(k_run_rw<M, 4, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
-        return launch(k_run_rw<M, 4, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
+        // (compile-time k-step counts at d = 16 NT and d = 16 (NT - 1) + 1 .. 4: launch_rw_ks, rmh_launch.hpp)
+        if (adapt) return launch_rw_ks<M, 4, true, true, false>(m, p, c, r, lds, st);
+        return launch_rw_ks<M, 4, false, true, false>(m, p, c, r, lds, st);
     })
 }
 

@@ -55,9 +55,9 @@ hipError_t launch_mix_rw(int NT, const MixArgs &m, const RwArgs &p, const ChainA
         const size_t lds = sizeof(double) * (tri_tiles(kNT) * 64 + icdf_doubles(c.nmode));
         if (r.pt_K > 0)
             return launch(k_run_rw<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
-        if (adapt)
-            return launch(k_run_rw<M, 4, true, false, false>, c.nblocks, 4, lds, st, m, p, c, r);
-        return launch(k_run_rw<M, 4, false, false, false>, c.nblocks, 4, lds, st, m, p, c, r);
+        // (compile-time k-step count at d = 16 (NT - 1) + 1 .. 4: launch_rw_ks, rmh_launch.hpp; not at d = 16 NT, see launch_hmc_ks)
+        if (adapt) return launch_rw_ks<M, 4, true, false, false, false>(m, p, c, r, lds, st);
+        return launch_rw_ks<M, 4, false, false, false, false>(m, p, c, r, lds, st);
     })
 }
 

@@ -43,6 +43,23 @@ static hipError_t launch_hmc_ks(const A &m, const HmcArgs &p, const ChainArgs &c
     return launch(k_run_hmc<M, NW, ADAPT, MASS>, c.nblocks, NW, lds, st, m, p, c, r);
 }
 
+// the same for k_run_rw<M, NW, ADAPT, PCN, false, LGLOBAL>: FULL at d = 16 NT, KSC = 4 (NT - 1) + 1 at d = 16 (NT - 1) + 1 .. 4
+template <class M, int NW, bool ADAPT, bool PCN, bool LGLOBAL, bool FULLOK = true, class A>
+static hipError_t launch_rw_ks(const A &m, const RwArgs &p, const ChainArgs &c, const RunArgs &r, size_t lds, hipStream_t st)
+{
+    constexpr int NT = M::T::S / 4;
+    if (!policy(RMH_POLICY_NO_TAIL)) {
+        if constexpr (FULLOK)
+            if (c.d == 16 * NT)
+                return launch(k_run_rw<M, NW, ADAPT, PCN, false, LGLOBAL, true>, c.nblocks, NW, lds, st, m, p, c, r);
+        if constexpr (NT >= 2) {
+            if (c.ks == 4 * (NT - 1) + 1)
+                return launch(k_run_rw<M, NW, ADAPT, PCN, false, LGLOBAL, false, 4 * (NT - 1) + 1>, c.nblocks, NW, lds, st, m, p, c, r);
+        }
+    }
+    return launch(k_run_rw<M, NW, ADAPT, PCN, false, LGLOBAL>, c.nblocks, NW, lds, st, m, p, c, r);
+}
+
 #define RMH_NT_DISPATCH(NT, ...)                     \
     switch (NT) {                                    \
     case 1: { constexpr int kNT = 1; __VA_ARGS__; }  \

@@ -201,11 +201,14 @@ struct PtLane {
 // FULL: d = 16 NT exactly (Gaussian model).  The dimension's k-step and word counts are then compile-time
 // constants: no wave-uniform test in front of the last four k-steps of every triangular product, no
 // coordinate selects in the normals (as the VALU-tail kernels have it for d = 16 NF + 1..4).
-template <class M, int NW, bool ADAPT, bool PCN = false, bool PT = false, bool LGLOBAL = false, bool FULL = false>
+// KSC (last parameter; FULL = true is KSC = 4 NT): the k-step count alone as a compile-time constant, e.g. 4 (NT - 1) + 1
+// at d = 16 (NT - 1) + 1 .. 4 for the models and proposals that have no VALU-tail kernel (launch_rw_ks, rmh_launch.hpp)
+template <class M, int NW, bool ADAPT, bool PCN = false, bool PT = false, bool LGLOBAL = false, bool FULL = false, int KSC = 0>
 __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m_in, RwArgs pr, ChainArgs ch_in, RunArgs run)
 {
     constexpr int NT = M::T::S / 4, S = M::T::S;
     using T = Tile<NT>;
+    static_assert(!(FULL && KSC > 0), "FULL is KSC = 4 NT with d and the word count on top");
     typename M::Args m = m_in;
     ChainArgs ch = ch_in;
     if constexpr (FULL) {
@@ -213,6 +216,9 @@ __global__ void __launch_bounds__(64 * NW) k_run_rw(typename M::Args m_in, RwArg
         ch.ks = S;
         ch.M = S / 2;
         m.ks = S;
+    } else if constexpr (KSC > 0) {
+        ch.ks = KSC;
+        m.ks = KSC;
     }
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const double *Limg = LGLOBAL ? pr.Ltiles : lds;

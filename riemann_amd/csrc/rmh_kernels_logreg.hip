@@ -31,7 +31,7 @@ hipError_t launch_logreg_rw(int NT, const LogRegArgs &m, const RwArgs &p, const 
         using M = LogRegModel<kNT>;
         const size_t lds = sizeof(double) * (M::lds_doubles(false) + icdf_doubles(c.nmode));
         if (r.pt_K > 0)
-            return launch(k_run_rw<M, 4, false, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
+            return launch(k_run_rw<M, 8, false, false, true, true>, c.nblocks, 8, lds, st, m, p, c, r);
         // eight waves per workgroup, as the HMC kernels (one workgroup per CU whatever the dimension: a second wave per
         // SIMD fills the barrier / s_waitcnt gaps of the stage loop; what the 256-register cap spills sits outside it)
         // (compile-time k-step counts at d = 16 NT and d = 16 (NT - 1) + 1 .. 4: launch_rw_ks, rmh_launch.hpp)

@@ -46,7 +46,7 @@ hipError_t launch_logreg_pcn(int NT, const LogRegArgs &m, const RwArgs &p, const
     RMH_NT_DISPATCH(NT, {
         using M = LogRegModel<kNT>;
         const size_t lds = sizeof(double) * (M::lds_doubles(false) + icdf_doubles(c.nmode));
-        if (r.pt_K > 0) return launch(k_run_rw<M, 4, false, true, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
+        if (r.pt_K > 0) return launch(k_run_rw<M, 8, false, true, true, true>, c.nblocks, 8, lds, st, m, p, c, r);
         if (adapt) return launch_rw_ks<M, 8, true, true, true>(m, p, c, r, lds, st);
         return launch_rw_ks<M, 8, false, true, true>(m, p, c, r, lds, st);
     })
@@ -92,8 +92,8 @@ hipError_t launch_logreg_hmc(int NT, const LogRegArgs &m, const HmcArgs &p, cons
             return launch(k_run_hmc<MF, NW, false, false>, c.nblocks, NW, lds, st, m, p, c, r);
         }
         if (r.pt_K > 0) { // parallel tempering: HMC / MALA (with or without a mass matrix) within the rungs
-            if (p.chM) return launch(k_run_hmc<M, 4, false, true, true>, c.nblocks, 4, lds, st, m, p, c, r);
-            return launch(k_run_hmc<M, 4, false, false, true>, c.nblocks, 4, lds, st, m, p, c, r);
+            if (p.chM) return launch(k_run_hmc<M, 8, false, true, true>, c.nblocks, 8, lds, st, m, p, c, r);
+            return launch(k_run_hmc<M, 8, false, false, true>, c.nblocks, 8, lds, st, m, p, c, r);
         }
         if (p.chM) { // mass-matrix variant
             if (adapt) return launch(k_run_hmc<M, NW, true, true>, c.nblocks, NW, lds, st, m, p, c, r);

@@ -286,11 +286,11 @@ def measure(name, a, ranks, steps, warmup, iters=0, with_cpu=True, with_ess=True
     if pt:   # N ladders of K replicas in S chain slots; streams keyed by global slot id
         from riemann_amd.samplers import PTSampler
         s = PTSampler(w["model"], w["proposal"], w["theta0"], betas=pt["betas"], Pswap=pt["pswap"],
-                      seed=a.seed, chain0=rank * a.chains)
+                      seed=a.seed, chain0=rank * a.chains, normals=a.normals)
         K = s.Ntemps
         bet = _lib.as_f64(s.betas)
     else:
-        s = ra.Sampler(w["model"], w["proposal"], w["theta0"], seed=a.seed, chain0=rank * N)
+        s = ra.Sampler(w["model"], w["proposal"], w["theta0"], seed=a.seed, chain0=rank * N, normals=a.normals)
     hist = C.c_void_p()
     if not a.no_record:
         _lib.call("rmh_history_create", s._state, iters + 1, iters, C.byref(hist))
@@ -387,6 +387,8 @@ def measure(name, a, ranks, steps, warmup, iters=0, with_cpu=True, with_ess=True
         out["pool"] = pooled
     if with_cpu and world == 1:   # the CPU leg is timed at N=1 only
         out["cpu_baseline"] = cpu_baseline(w, a.seed)
+    if a.normals != "f32x2":
+        out["config"]["normals"] = a.normals
     if pt:
         out["config"]["ladders_per_gpu"] = N // K
         out["config"]["temperatures"] = K
@@ -421,6 +423,9 @@ def main():
     ap.add_argument("--no-ess", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the short runs of the other configs")
     ap.add_argument("--no-record", action="store_true", help="do not record the history (diagnostic)")
+    ap.add_argument("--normals", default="f32x2", choices=["f32x2", "f64"],
+                    help="resolution of the stream's normals (Sampler(..., normals=...)); f64: one normal per 64-bit word "
+                         "(not for changepoint_rw's specialised kernel: that workload then runs the generic one)")
     a = ap.parse_args()
 
     from riemann_amd import _lib

@@ -49,5 +49,19 @@ def test_sampling_gauss2d(nchains=4096):
                  np.round(chain.mean(axis=(0, 1)), 3), sampler.last_run_ms))
 
 
+def float64_normals(nchains=4096):
+    """The same walk drawing its normals at float64 resolution (one per 64-bit stream word instead of two):
+    Sampler(..., normals="f64") -- what np.random.normal gives the reference's proposals."""
+    model = benchmark_gauss2d_corr
+    for mode in ("f32x2", "f64"):
+        sampler = Sampler(model, MetropolisRandomWalk(np.eye(2)), np.ones((nchains, 2)), seed=0, normals=mode)
+        sampler.run(10000, 1000, 1)
+        chain = sampler._chain_thetas
+        print("normals=%-6s accept = %.3f  mean = %s  var = %s  %.1f ms on the GPU"
+              % (mode, sampler._chain_accept.mean(), np.round(chain.mean(axis=(0, 1)), 3),
+                 np.round(chain.var(axis=(0, 1)), 3), sampler.last_run_ms))
+
+
 if __name__ == "__main__":
     test_sampling_gauss2d()
+    float64_normals()

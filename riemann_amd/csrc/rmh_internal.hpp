@@ -216,9 +216,10 @@ hipError_t launch_cp_eval(int k, const CpArgs &m, const ChainArgs &c, double *lp
                           double *llik, double *lpost, hipStream_t st);
 hipError_t launch_cp_rw(int k, const CpArgs &m, const RwArgs &p, const ChainArgs &c,
                         const RunArgs &r, hipStream_t st);
-// sufficient-statistics kernel (diagonal proposal, alpha = 1, plain random walk)
+// sufficient-statistics kernels (diagonal proposal, alpha = 1, plain random walk; adapt: the chains' own scales -- on the
+// one-lane-per-chain kernel only, hipErrorNotReady where that one does not apply)
 hipError_t launch_cp_rw_ss(int k, const CpArgs &m, const RwArgs &p, const ChainArgs &c,
-                           const RunArgs &r, hipStream_t st);
+                           const RunArgs &r, hipStream_t st, bool adapt = false);
 
 // device-side covariance update of the pooled AdaptCov (k_acov_update, rmh_kernels_mfma.hip)
 struct AcovUpdateArgs {

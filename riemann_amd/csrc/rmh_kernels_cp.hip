@@ -571,9 +571,13 @@ __global__ void __launch_bounds__(512, 4) k_cp_rw_ss(CpArgs m, RwArgs pr, ChainA
 // the diagonal factor of the other blocks' coordinates by 0 -- fma(0, xi, theta) = theta, the bits the
 // zeroed normals of the four-lane kernel give.  The three blocks are the reference's (k changepoint
 // positions, k + 1 heights, sigma): their ends are compile-time constants here (the launcher checks).
-template <int KC, int STEPS, int S2 = 0, bool BLK = false>
+// ADAPT (end of round 3): AdaptScaleRandomWalk, the chain's own scale (AdaptScale, rmh_run.hpp) -- one lane is one chain here,
+// so the three state values sit in the lane: theta' = theta + scale (L xi) with the unscaled diagonal, operation for
+// operation what k_run_rw<CpPolicy, ..., ADAPT> does (5.5e9 it/s there, the generic four-lanes-per-chain kernel).
+template <int KC, int STEPS, int S2 = 0, bool BLK = false, bool ADAPT = false>
 __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainArgs ch, RunArgs run)
 {
+    static_assert(!(BLK && ADAPT), "the block mixture has no scale adaptation");
     constexpr int D = 2 * KC + 2, KP = KC + 1;
     constexpr int NT = (D + 15) / 16, S = 4 * NT, NS = (D + 3) / 4;
     constexpr int DE = 2 * ((D + (BLK ? 5 : 2)) / 2);   // doubles read back per chain: D normals + the uniform(s), even
@@ -606,6 +610,8 @@ __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainAr
 #pragma unroll
     for (int j = 0; j < D; ++j) th[j] = live ? ch.theta[(int64_t)j * ch.ld + c] : 0.0;
     double lp = live ? ch.logpost[c] : 0.0;
+    AdaptScale ad{0.0, 0.0, 1.0};
+    if (ADAPT && live) ad.load(ch, c);
     Xo st[4];                                      // pass b: chain 16 (blk0 + b) + cl, sub-stream g
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -640,6 +646,11 @@ __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainAr
         arrived(ldg[j]);
     }
     arrived(lp);
+    if (ADAPT) {
+        arrived(ad.n);
+        arrived(ad.acc);
+        arrived(ad.scale);
+    }
 #pragma unroll
     for (int b = 0; b < 4; ++b) arrived(st[b]);
 
@@ -701,6 +712,12 @@ __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainAr
             const double mb[3] = {pk == 0 ? 1.0 : 0.0, pk == 1 ? 1.0 : 0.0, pk == 2 ? 1.0 : 0.0};
 #pragma unroll
             for (int j = 0; j < D; ++j) tp[j] = fma_(ldg[j] * mb[j < KC ? 0 : (j < D - 1 ? 1 : 2)], dr[j], th[j]);
+        } else if (ADAPT) { // theta + scale * (L xi): product, product, sum -- as the generic kernel rounds them
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double lx = ldg[j] * dr[j];
+                tp[j] = th[j] + ad.scale * lx;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < D; ++j) tp[j] = fma_(ldg[j], dr[j], th[j]);
@@ -791,6 +808,7 @@ __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainAr
 #pragma unroll
         for (int j = 0; j < D; ++j) th[j] = ok ? tp[j] : th[j];
         lp = ok ? lpp : lp;
+        if (ADAPT) ad.adapt(ok, ch.adapt_target);   // adapt() after the step, sampler.py:88
         if (run.h_accept && live) run.h_accept[t * ch.ld + c] = ok ? 1 : 0;
         rec(t + 1);
     }
@@ -798,15 +816,18 @@ __global__ void __launch_bounds__(256) k_cp_rw_ss64(CpArgs m, RwArgs pr, ChainAr
 #pragma unroll
         for (int j = 0; j < D; ++j) ch.theta[(int64_t)j * ch.ld + c] = th[j];
         ch.logpost[c] = lp;
+        if (ADAPT) ad.store(ch, c);
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b)
         if (blk0 + b < ch.nblocks) xo_store(ch.rng, ch.nslots, (blk0 + b) * 64 + lane, st[b]);
 }
 
+// adapt: the AdaptScale variant exists on the one-lane-per-chain kernel only (hipErrorNotReady: not applicable here,
+// the caller takes the generic kernel)
 template <int KC>
 static hipError_t cp_rw_ss_launch(const CpArgs &m, const RwArgs &p, const ChainArgs &c,
-                                  const RunArgs &r, hipStream_t st)
+                                  const RunArgs &r, hipStream_t st, bool adapt)
 {
     constexpr int D = 2 * KC + 2;
     const int np = (1 << m.ss_steps) - 1;
@@ -834,6 +855,12 @@ static hipError_t cp_rw_ss_launch(const CpArgs &m, const RwArgs &p, const ChainA
         hipLaunchKernelGGL((k_cp_rw_ss64<KC, __VA_ARGS__>), grid, dim3(64 * nw), lds, st, m, p, c, r);    \
         return hipGetLastError();                                                                        \
     }
+            if (adapt) { // (and here)
+                if (blk) return hipErrorNotReady;
+                if (buckets && m.ss_s2 == 2) RMH_CP_SS64(0, 2, false, true)
+                if (buckets && m.ss_s2 == 3) RMH_CP_SS64(0, 3, false, true)
+                RMH_CP_SS64(0, 0, false, true)
+            }
             if (blk) { // fewer instantiations: the bucket table when the model has one, else run-time depth
                 if (buckets && m.ss_s2 == 2) RMH_CP_SS64(0, 2, true)
                 if (buckets && m.ss_s2 == 3) RMH_CP_SS64(0, 3, true)
@@ -850,6 +877,7 @@ static hipError_t cp_rw_ss_launch(const CpArgs &m, const RwArgs &p, const ChainA
 #undef RMH_CP_SS64
         }
     }
+    if (adapt) return hipErrorNotReady;
     constexpr int TS = 2 * (((D + 1) / 2) | 1), BS = 2 * (KC | 1);
     const int nw = 8;
     const size_t lds = sizeof(double) * ((size_t)2 * np + 2 + kIcdfDoubles + (size_t)nw * 16 * (TS + BS));
@@ -1700,9 +1728,9 @@ hipError_t launch_cp_rw(int k, const CpArgs &m, const RwArgs &p, const ChainArgs
 }
 
 hipError_t launch_cp_rw_ss(int k, const CpArgs &m, const RwArgs &p, const ChainArgs &c,
-                           const RunArgs &r, hipStream_t st)
+                           const RunArgs &r, hipStream_t st, bool adapt)
 {
-    RMH_CP_DISPATCH(cp_rw_ss_launch, m, p, c, r, st)
+    RMH_CP_DISPATCH(cp_rw_ss_launch, m, p, c, r, st, adapt)
 }
 
 // the generic fused kernels over the changepoint policy: variant 1 = AdaptScale random walk,

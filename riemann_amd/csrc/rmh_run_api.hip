@@ -483,8 +483,15 @@ static int run_impl(rmh_model_t m, rmh_proposal_t p, rmh_state_t s, int64_t T, i
             ra.Ltail = p->d_Ltail;   // d = 97..100: rows 96..99 on the VALU instead of a 7th row tile
             e = launch_gauss_rw_tail(m->ga, ra, c, r, adapt, g_stream);
         } else if (m->kind == kGauss) e = launch_gauss_rw(m->NT, m->ga, ra, c, r, adapt, g_stream);
-        else if (m->kind == kChangepoint && (adapt || c.nmode)) // (64-bit normals: the generic kernel over the changepoint policy)
-            e = launch_cp_generic(m->k, m->ca, ra, c, r, adapt ? 1 : 0, g_stream);
+        else if (m->kind == kChangepoint && (adapt || c.nmode)) { // (64-bit normals: the generic kernel over the changepoint policy)
+            e = hipErrorNotReady;
+            if (adapt && !c.nmode && p->nblk == 0 && p->L_is_diag && m->ca.ss_xp && m->ca.alpha_m1 == 0.0 &&
+                !policy(RMH_POLICY_CP_NO_SS)) { // cfg 5's conditions: the one-lane-per-chain kernel with the chains' own scales
+                ra.Ldiag = p->d_Ldiag;          // (unscaled in this mode, as the tile image)
+                e = launch_cp_rw_ss(m->k, m->ca, ra, c, r, g_stream, true);
+            }
+            if (e == hipErrorNotReady) e = launch_cp_generic(m->k, m->ca, ra, c, r, adapt ? 1 : 0, g_stream);
+        }
         else if (m->kind == kChangepoint && p->L_is_diag && m->ca.ss_xp && m->ca.alpha_m1 == 0.0 &&
                  !policy(RMH_POLICY_CP_NO_SS)) {
             // BASELINE cfg 5 (and the block-mixture proposal at fixed k): diagonal proposal factor,

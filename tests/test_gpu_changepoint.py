@@ -277,3 +277,42 @@ def test_one_lane_per_chain_kernel_search_variants_vs_oracle(ra, orc, case):
     # bound alone fails by chance on a value of 1e-4 (seen: 5e-10 relative = 5e-14 absolute)
     np.testing.assert_allclose(s._chain_logpost[fin], hl[fin], rtol=RTOL, atol=1e-11)
     assert 0.01 < acc.mean() < 0.95
+
+
+@pytest.mark.parametrize("k,n", [(5, 100), (3, 60), (8, 100)])
+def test_adapted_scale_walk_on_the_one_lane_per_chain_kernel_vs_oracle_and_generic_kernel(ra, orc, k, n):
+    """AdaptScaleRandomWalk on the changepoint model: k_cp_rw_ss64<..., ADAPT> (forced here by the kernel policy; by
+    itself it takes over at 65 536 chains) against the oracle and against the generic kernel over the changepoint
+    policy -- accept masks, states, log posteriors and the chains' adapted scales."""
+    from riemann_amd._lib import kernel_policy
+    from riemann_amd import workloads as W
+    from riemann_amd.models import ChangepointRegression1D
+    from riemann_amd.proposals import AdaptScaleRandomWalk
+    g = np.random.default_rng(100 * k + n)
+    x, y, truth, cdiag = W.changepoint_data(seed=11, k=k, n=n)
+    d, N, T = 2 * k + 2, 700, 60
+    th0 = truth + 0.01 * g.standard_normal((N, d))
+    th0[:, :k] = np.sort(th0[:, :k], axis=1)
+    Cp = 0.1 * np.diag(cdiag)
+    out = {}
+    for pol in (("CP_SS64",), ()):
+        with kernel_policy(*pol):
+            p = AdaptScaleRandomWalk(Cp)
+            s = ra.Sampler(ChangepointRegression1D(x, y, 1.0, 3.0, 5.0, 2 * k, 1, 1, k=k), p, th0, seed=4, chain0=9)
+            s.run(T // 2)
+            a1 = s._chain_accept.copy()
+            s.run(T - T // 2)                      # the adaptation state persists across run() calls
+            out[pol] = (np.concatenate([a1, s._chain_accept]), s._chain_thetas.copy(), s._chain_logpost.copy(),
+                        np.array(p.scale).copy(), np.array(p.Nsamples).copy())
+    om = orc.Changepoint(x, y, k, 1.0, 3.0, 5.0, 1.0, 1.0)
+    th, st, ad = th0.copy(), orc.rng_seed(4, N, chain0=9), orc.new_adapt_state(N)
+    ht, hl, acc = orc.run(om, orc.set_adapt(orc.RandomWalk(Cp), 0.25), th, om.log_posterior(th), st, T, adapt=ad)
+    for pol in out:
+        a, th_, lp_, sc, ns = out[pol]
+        np.testing.assert_array_equal(a, acc)
+        np.testing.assert_allclose(th_, ht[T // 2:], rtol=RTOL, atol=1e-12)
+        fin = np.isfinite(hl[T // 2:])
+        np.testing.assert_allclose(lp_[fin], hl[T // 2:][fin], rtol=RTOL, atol=1e-11)
+        np.testing.assert_allclose(sc, ad[:, 2], rtol=1e-12)
+        np.testing.assert_array_equal(ns, ad[:, 0])
+    assert 0.05 < acc.mean() < 0.9
